@@ -1,0 +1,222 @@
+/*
+ * poroel_hip.h — C-ABI of the MI355X-native fixed-stress Biot hot path.
+ *
+ * This is the drop-in boundary for the per-timestep "assemble + Krylov solve"
+ * path of ishovkun/poroelasticity-dealii.  The reference has no FFI; the path
+ * sits behind public member functions of three class templates that are only
+ * called from PoroElasticProblem<dim>::run() (lib/include/PoroelasticityFSS.h:294-415).
+ * Every entry point below names the reference member (file:line) it replaces.
+ * Signatures use plain pointers and sizes only (no C++/torch types); the
+ * library owns all device memory behind the opaque handle, the caller owns the
+ * host arrays it passes in.  All calls are synchronous at return.
+ *
+ * Conventions fixed by this ABI (the reference leaves them to deal.II):
+ *   - local scalar nodes of a cell are lexicographic on the (k+1)^dim tensor
+ *     grid, x fastest; local vector dof i = scalar_node*dim + component
+ *     (FESystem::system_to_component_index, PoroElasticDisplacementSolver.h:218);
+ *   - cell vertices are lexicographic (v = ix + 2*iy + 4*iz), as deal.II;
+ *   - faces: f = 2*normal_direction + (0 low side | 1 high side), as deal.II
+ *     GeometryInfo; hyper_rectangle(colorize) boundary ids equal f
+ *     (PoroelasticityFSS.h:430-432, input.data:8-11);
+ *   - quadrature points are tensorised Gauss-Legendre on [0,1], x fastest
+ *     (QGauss<dim>, PoroElasticDisplacementSolver.h:159);
+ *   - all floating point data is IEEE double; dof/cell indices are int32,
+ *     CSR row pointers int64.
+ *
+ * Return codes: 0 ok; >0 a Krylov solve hit its iteration cap (the analogue of
+ * deal.II SolverControl::NoConvergence, info is filled); <0 invalid argument,
+ * HIP or RCCL failure (message via poro_last_error()).
+ */
+#ifndef POROEL_HIP_H
+#define POROEL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PORO_ABI_VERSION 1
+
+/* Reference-cell tables: exactly the numbers the reference pulls out of
+ * FEValues / FEFaceValues (PoroElasticDisplacementSolver.h:162-173,
+ * StrainProjector.h:127-134, MatrixCreator calls PoroElasticPressureSolver.h:96-101).
+ * "q1" is the Q1 Lagrange basis on the cell vertices: it is both MappingQ1 and
+ * the pressure element FE_Q(1) (PoroElasticPressureSolver.h:20,57). */
+typedef struct poro_fe_tables {
+  int32_t nq_u;  /* (k_u+1)^dim  volume points, QGauss(fe.degree+1) of u      */
+  int32_t nq_p;  /* 2^dim        volume points, QGauss(2) of p                */
+  int32_t nq_f;  /* (k_u+1)^(dim-1) face points                               */
+  int32_t ns_u;  /* scalar nodes per cell of u: (k_u+1)^dim                   */
+  int32_t ns_p;  /* = number of vertices 2^dim                                */
+  const double *w_qu;      /* [nq_u]                                          */
+  const double *w_qp;      /* [nq_p]                                          */
+  const double *w_qf;      /* [nq_f]                                          */
+  const double *u_qu;      /* [nq_u][ns_u]        phi^u_s(xi_q)               */
+  const double *du_qu;     /* [nq_u][ns_u][dim]   d phi^u_s / d xi_d          */
+  const double *du_qp;     /* [nq_p][ns_u][dim]                               */
+  const double *q1_qu;     /* [nq_u][ns_p]                                    */
+  const double *dq1_qu;    /* [nq_u][ns_p][dim]                               */
+  const double *q1_qp;     /* [nq_p][ns_p]                                    */
+  const double *dq1_qp;    /* [nq_p][ns_p][dim]                               */
+  const double *u_qf;      /* [2*dim][nq_f][ns_u] u shape values on face f    */
+  const double *dq1_qf;    /* [2*dim][nq_f][ns_p][dim]                        */
+} poro_fe_tables;
+
+/* Constant coefficients, = InputDataPoroel after compute_derived_parameters
+ * (InputDataPoroel.h:213-222; units :162,168). */
+typedef struct poro_material {
+  double lame_lambda;   /* data.lame_constant  */
+  double shear_G;       /* data.shear_modulus  */
+  double biot_alpha;    /* data.biot_coef      */
+  double bulk_K;        /* data.bulk_modulus (drained)  */
+  double biot_M;        /* data.m_modulus      */
+  double k_over_mu;     /* data.perm/data.visc */
+  double r_well;        /* data.r_well         */
+  double flow_rate;     /* data.flow_rate      */
+} poro_material;
+
+/* Optional: the mesh is a uniform box n[0] x n[1] (x n[2]) with lexicographic
+ * node numbering and dof = node*dim + comp (u), dof = vertex (p).  Enables the
+ * matrix-free operator.  hyper_rectangle + refine_global meshes
+ * (PoroelasticityFSS.h:418-435) are of this kind. */
+typedef struct poro_structured {
+  int32_t enabled;
+  int32_t n[3];
+  double  origin[3];
+  double  h[3];
+} poro_structured;
+
+/* Slab partition of a structured box over ranks.  The local mesh is
+ * the rank's slab as a standalone box; node planes at the low / high end in the
+ * slowest direction are shared with the neighbour rank when has_lower/has_upper. */
+typedef struct poro_partition {
+  int32_t rank, n_ranks;
+  int32_t has_lower, has_upper;
+  int64_t plane_u;   /* u dofs on one interface plane  */
+  int64_t plane_p;   /* p dofs on one interface plane  */
+} poro_partition;
+
+typedef struct poro_desc {
+  int32_t abi_version;
+  int32_t dim;        /* 2 | 3 */
+  int32_t degree_u;   /* 1 | 2  (the reference hard-wires 2, PoroElasticDisplacementSolver.h:67) */
+  int32_t degree_p;   /* 1 */
+  int64_t n_cells, n_vertices, n_dofs_u, n_dofs_p;
+  const double  *vertex_coords;  /* [n_vertices][dim]                       */
+  const int32_t *cell_vertices;  /* [n_cells][2^dim]                        */
+  const int32_t *cell_dofs_u;    /* [n_cells][dim*ns_u]  cell->get_dof_indices (:279) */
+  const int32_t *cell_dofs_p;    /* [n_cells][ns_p]      (StrainProjector.h:191)      */
+  poro_fe_tables fe;
+  /* boundary faces, for the Neumann term (:249-277) */
+  int64_t n_bfaces;
+  const int32_t *bface_cell, *bface_local, *bface_id;
+  /* closed Dirichlet constraint list = `constraints` after :117-136 */
+  int64_t n_dirichlet;
+  const int32_t *dirichlet_dof;
+  const double  *dirichlet_value;
+  /* Neumann conditions (BoundaryConditions.h:45-62) */
+  int32_t n_neumann;
+  const int32_t *neumann_label, *neumann_component;
+  const double  *neumann_value;
+  poro_material   mat;
+  poro_structured box;
+  poro_partition  part;
+} poro_desc;
+
+/* Krylov controls.  Reference values: displacement abs 1e-12, 1000 its
+ * (PoroElasticDisplacementSolver.h:298-299); pressure / projection
+ * rel 1e-8*||rhs||, 1000 its (PoroElasticPressureSolver.h:175, StrainProjector.h:209).
+ * Stopping test is on the recursively updated residual: ||g||_2 <= max(abs_tol, rel_tol*||b||_2). */
+typedef struct poro_solver_opts {
+  double  abs_tol;
+  double  rel_tol;
+  int32_t max_iter;
+  int32_t preconditioner;  /* PORO_PREC_* */
+} poro_solver_opts;
+
+enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1 };
+enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };
+enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_JACOBIAN_P = 3 };
+enum { PORO_VEC_U = 0, PORO_VEC_RHS_U = 1, PORO_VEC_P = 2, PORO_VEC_P_OLD = 3, PORO_VEC_DP = 4,
+       PORO_VEC_RESIDUAL_P = 5, PORO_VEC_EPSV = 6, PORO_VEC_EPSV0 = 7, PORO_VEC_SOURCE_P = 8,
+       PORO_VEC_STRAIN0 = 16 /* + packed symmetric entry (TensorIndexer.h:24-31) */,
+       PORO_VEC_PROJ_RHS0 = 32 /* + entry */, PORO_VEC_DIAG_U = 48 };
+
+typedef struct poro_solve_info {
+  int32_t iterations;
+  int32_t converged;
+  double  initial_residual;
+  double  final_residual;
+  double  seconds;       /* wall time of the solve on device */
+  int64_t operator_applications;
+} poro_solve_info;
+
+typedef struct poro_ctx poro_ctx;
+
+const char *poro_last_error(void);
+int  poro_abi_version(void);
+
+/* setup_dofs of the three solvers (PoroElasticDisplacementSolver.h:106-153,
+ * PoroElasticPressureSolver.h:68-111, StrainProjector.h:82-98): builds sparsity,
+ * mass / Laplace matrices, constraint tables, device vectors.  operator_mode
+ * selects assembled CSR or the matrix-free A_u (needs desc->box.enabled). */
+int  poro_ctx_create(const poro_desc *desc, int device, int operator_mode, poro_ctx **out);
+void poro_ctx_destroy(poro_ctx *ctx);
+
+/* multi-GPU wiring.  id is the 128-byte ncclUniqueId from rank 0. */
+int  poro_comm_unique_id(void *id128);
+int  poro_ctx_comm_init_rccl(poro_ctx *ctx, const void *id128);
+/* host-staged exchange through caller callbacks (tests: 2 ranks on one GPU, gloo). */
+typedef void (*poro_allreduce_fn)(double *buf, int32_t n, void *user);
+typedef void (*poro_sendrecv_fn)(const double *send, double *recv, int64_t n, int32_t peer, void *user);
+int  poro_ctx_comm_init_callbacks(poro_ctx *ctx, poro_allreduce_fn ar, poro_sendrecv_fn sr, void *user);
+
+/* vectors live on the device between calls; these move them across the boundary */
+int  poro_vec_set(poro_ctx *ctx, int which, const double *host, int64_t n);
+int  poro_vec_get(poro_ctx *ctx, int which, double *host, int64_t n);
+int  poro_vec_fill(poro_ctx *ctx, int which, double value);
+int  poro_vec_copy(poro_ctx *ctx, int dst, int src);               /* e.g. old_solution = solution (PoroelasticityFSS.h:342) */
+int  poro_vec_axpy(poro_ctx *ctx, int y, double a, int x);         /* solution += solution_update (:379)                    */
+int  poro_vec_norm(poro_ctx *ctx, int which, double *l2, double *linf);
+
+/* PoroElasticDisplacementSolver<dim>::assemble_system (:155-291); pressure taken from PORO_VEC_P.
+ * rebuild_matrix mirrors `rebuild_system_matrix` (:280): 1 = (re)build A_u (CSR values, or the
+ * matrix-free operator data + diagonal) and the constant Dirichlet lifting, 0 = RHS only. */
+int  poro_disp_assemble_system(poro_ctx *ctx, int rebuild_matrix);
+/* PoroElasticDisplacementSolver<dim>::solve (:294-307): PCG, warm start from PORO_VEC_U, then constraints.distribute. */
+int  poro_disp_solve(poro_ctx *ctx, const poro_solver_opts *opts, poro_solve_info *info);
+
+/* PoroElasticPressureSolver<dim>::assemble_residual (:113-155) from PORO_VEC_{P,P_OLD,EPSV,EPSV0}; l2 = residual.l2_norm() (PoroelasticityFSS.h:364) */
+int  poro_pres_assemble_residual(poro_ctx *ctx, double time_step, double *l2);
+/* PoroElasticPressureSolver<dim>::assemble_jacobian (:158-169) */
+int  poro_pres_assemble_jacobian(poro_ctx *ctx, double time_step);
+/* PoroElasticPressureSolver<dim>::solve (:172-185): J dp = R into PORO_VEC_DP (warm start) */
+int  poro_pres_solve(poro_ctx *ctx, const poro_solver_opts *opts, poro_solve_info *info);
+/* PoroElasticPressureSolver<dim>::update_volumetric_strain (:187-194): eps_v += (alpha/K) dp */
+int  poro_pres_update_volumetric_strain(poro_ctx *ctx);
+
+/* StrainProjector<dim>::assemble_projection_matrix (:101-106) */
+int  poro_proj_assemble_matrix(poro_ctx *ctx);
+/* StrainProjector<dim>::assemble_projection_rhs (:109-198); tensor_components are full indices a*dim+b */
+int  poro_proj_assemble_rhs(poro_ctx *ctx, const int32_t *tensor_components, int32_t n_comp);
+/* StrainProjector<dim>::solve_projection_system (:201-232); rhs_entry = packed symmetric entry */
+int  poro_proj_solve(poro_ctx *ctx, int32_t rhs_entry, const poro_solver_opts *opts, poro_solve_info *info);
+/* PoroElasticProblem<dim>::get_volumetric_strain (PoroelasticityFSS.h:179-186): eps_v = sum of normal strains */
+int  poro_get_volumetric_strain(poro_ctx *ctx);
+
+/* parity / measurement hooks */
+int  poro_export_csr_size(poro_ctx *ctx, int which, int64_t *n_rows, int64_t *nnz);
+int  poro_export_csr(poro_ctx *ctx, int which, int64_t *row_ptr, int32_t *col, double *val);
+/* y = A x with the operator `which` (A_U honours the ctx operator mode); host in/out */
+int  poro_apply_operator(poro_ctx *ctx, int which, const double *x_host, double *y_host);
+/* repeat y = A_u x `reps` times on device-resident synthetic x; returns mean seconds per application (HIP events) */
+int  poro_bench_operator(poro_ctx *ctx, int which, int operator_mode, int reps, double *seconds_per_apply);
+/* accumulated HIP-event time (s) and launch count of the named kernel family since the last reset */
+int  poro_timers_reset(poro_ctx *ctx);
+int  poro_timers_get(poro_ctx *ctx, const char *name, double *seconds, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POROEL_HIP_H */

@@ -1,0 +1,160 @@
+// Shared declarations of the HIP back end (gfx950 only): device buffers, the context behind the
+// opaque poro_ctx handle and the launch wrappers of every kernel family.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <type_traits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/poroel_hip.h"
+
+namespace poro {
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define PORO_HIP(x)                                                                                   \
+  do { hipError_t e_ = (x); if (e_ != hipSuccess) throw poro::Error(std::string(#x) + " -> " + hipGetErrorString(e_)); } while (0)
+
+template <class T> struct DevBuf {
+  T *p = nullptr; size_t n = 0;
+  DevBuf() = default; DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void alloc(size_t n_) { release(); n = n_; if (n) PORO_HIP(hipMalloc((void **)&p, n * sizeof(T))); }
+  void zero(hipStream_t s) { if (n) PORO_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+  void upload(const T *h, size_t n_) { alloc(n_); if (n) PORO_HIP(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice)); }
+  void upload(const std::vector<T> &h) { upload(h.data(), h.size()); }
+};
+
+constexpr int kMaxPartials = 1024;   // grid cap of every reducing kernel = number of per-block partial sums
+constexpr int kScalarSlots = 32;
+
+// device-resident scalars of a PCG solve (no host round trip inside the iteration)
+struct PcgScalars {
+  double dh, gg, gz;         // reductions of the current iteration (after all-reduce)
+  double gh;                 // g.z of the previous iteration
+  double alpha, beta;
+  double tol, res0, res;
+  int32_t it, done, converged, max_iter;
+};
+
+struct FeTablesDev {   // device copies of poro_fe_tables
+  int nq_u, nq_p, nq_f, ns_u, ns_p;
+  const double *w_qu, *w_qp, *w_qf, *u_qu, *du_qu, *du_qp, *q1_qu, *dq1_qu, *q1_qp, *dq1_qp, *u_qf, *dq1_qf;
+};
+
+struct CsrDev {
+  int64_t n = 0, nnz = 0;
+  DevBuf<int64_t> rp; DevBuf<int32_t> col; DevBuf<int64_t> diag_pos;
+  int lanes_per_row = 8;
+};
+
+struct Timer { double seconds = 0; int64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+
+struct Comm {
+  poro_partition part{};
+  // RCCL (resolved at run time from librccl.so.1)
+  void *nccl_comm = nullptr;
+  // host-staged callbacks (tests)
+  poro_allreduce_fn ar = nullptr; poro_sendrecv_fn sr = nullptr; void *user = nullptr;
+  DevBuf<double> recv_lo, recv_hi; std::vector<double> hsend, hrecv;
+  bool multi() const { return part.n_ranks > 1; }
+};
+
+struct BoxDev { int enabled = 0; int n[3] = {1, 1, 1}; int nn[3] = {1, 1, 1}; double h[3] = {1, 1, 1}; };
+
+}  // namespace poro
+
+struct poro_ctx {
+  int device = 0, operator_mode = PORO_OP_CSR;
+  hipStream_t stream = nullptr;
+  int dim = 2, k_u = 2, ns_u = 9, ns_p = 4, dpc_u = 18, dpc_p = 4, nv = 4;
+  int64_t n_cells = 0, n_u = 0, n_p = 0;
+  poro_material mat{};
+  poro::BoxDev box;
+  poro::Comm comm;
+  // mesh / dof data
+  poro::DevBuf<int32_t> cell_dofs_u, cell_dofs_p, color_cells;
+  poro::DevBuf<double> cell_X, tables;
+  poro::FeTablesDev fe{};
+  std::vector<int64_t> color_off;            // host offsets into color_cells
+  poro::DevBuf<uint8_t> dir_mask; poro::DevBuf<double> dir_val;
+  std::vector<int32_t> h_dir_dof; std::vector<double> h_dir_val;
+  poro::DevBuf<int32_t> bface_cell, bface_local, bface_id, neu_label, neu_comp; poro::DevBuf<double> neu_val;
+  int64_t n_bfaces = 0; int n_neumann = 0;
+  // matrices
+  poro::CsrDev Ap, Au;                       // pressure pattern (mass, Laplace, Jacobian share it), displacement pattern
+  poro::DevBuf<double> Mp, Kp, Jp, Au_val;
+  bool projection_matrix_ready = false;
+  poro::DevBuf<double> Ke;                   // reference element matrix of the matrix-free operator
+  // vectors (ids of include/poroel_hip.h)
+  std::map<int, poro::DevBuf<double>> vec;
+  poro::DevBuf<double> lift_u, neumann_u, diag_u, diag_u_local, diag_J, diag_M, src_local;
+  poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
+  poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
+  bool matrix_built = false;
+  // timing
+  bool timing = false; std::map<std::string, poro::Timer> timers;
+  double jac_dt = -1;
+};
+
+namespace poro {
+
+// ---- kernels_la.hip -----------------------------------------------------------------------------
+void la_fill(hipStream_t s, double *x, double v, int64_t n);
+void la_copy(hipStream_t s, double *y, const double *x, int64_t n);
+void la_axpy(hipStream_t s, double *y, double a, const double *x, int64_t n);
+void la_add_range(hipStream_t s, double *y, const double *x, int64_t n);
+// partials-based reductions; results land in red[slot..] after la_reduce_finish
+void la_dot_partials(hipStream_t s, const double *a, const double *b, int64_t n, double *partials /*[kMaxPartials]*/);
+void la_norm_partials(hipStream_t s, const double *a, int64_t n, double *partials_l2, double *partials_inf);
+void la_reduce_finish(hipStream_t s, const double *partials, int n_sets, double *red /*[n_sets]*/, int max_not_sum_mask);
+void la_csr_spmv(hipStream_t s, const CsrDev &A, const double *val, const double *x, double *y);
+// R = -(M t + kappa K p + src)
+void la_csr_residual(hipStream_t s, const CsrDev &A, const double *M, const double *K, double kappa, const double *t, const double *p,
+                     const double *src, double *R);
+void la_pressure_tmp(hipStream_t s, double *t, const double *ev, const double *ev0, const double *p, const double *p_old, double c1, double c2, int64_t n);
+void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, double a, double kappa, int64_t nnz);
+void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag);
+void la_sum_strains(hipStream_t s, double *ev, const double *const *strains, int n, int64_t len);
+void la_set_constrained(hipStream_t s, double *x, const uint8_t *mask, const double *val, int64_t n);
+void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const double *neumann, const uint8_t *mask, int64_t n);
+// PCG pieces (device-side control, see solver in ctx.hip)
+void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, int64_t n);
+void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials);
+void pcg_update_xg(hipStream_t s, const PcgScalars *sc, double *x, double *g, const double *d, const double *h, const double *diag, int prec,
+                   int64_t n, int64_t n_owned, double *partials /*2 sets*/);
+void pcg_update_d(hipStream_t s, const PcgScalars *sc, double *d, const double *g, const double *diag, int prec, int64_t n);
+void pcg_first_direction(hipStream_t s, double *d, const double *g, const double *diag, int prec, int64_t n, int64_t n_owned, double *partials /*2 sets: gg, gz*/);
+void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red);
+void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red /*bb, gg, gz*/, double abs_tol, double rel_tol, int max_iter);
+void pcg_scalars_alpha(hipStream_t s, PcgScalars *sc, const double *red /*dh*/);
+void pcg_scalars_beta(hipStream_t s, PcgScalars *sc, const double *red /*gg, gz*/);
+
+// ---- kernels_asm.hip ----------------------------------------------------------------------------
+struct AsmArgs {
+  int dim, k_u, ns_u, ns_p, nv, dpc_u;
+  FeTablesDev fe;
+  const int32_t *cell_dofs_u, *cell_dofs_p; const double *cell_X;
+  const uint8_t *dir_mask; const double *dir_val;
+  poro_material mat;
+};
+void asm_u_matrix(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t n_cells, const int64_t *rp, const int32_t *col, double *val, double *lift);
+void asm_u_element_matrix(hipStream_t s, const AsmArgs &a, int32_t cell, double *Ke);
+void asm_u_rhs(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t n_cells, const double *p, double *rhs);
+void asm_u_neumann(hipStream_t s, const AsmArgs &a, int64_t n_bfaces, const int32_t *bf_cell, const int32_t *bf_local, const int32_t *bf_id,
+                   int n_neu, const int32_t *label, const int32_t *comp, const double *value, double *rhs);
+void asm_p_matrices(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t n_cells, const int64_t *rp, const int32_t *col, double *M, double *K, double *src);
+void asm_proj_rhs(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t n_cells, const double *u, int n_comp, const int32_t *comps /*host*/,
+                  double *const *rhs /*host array of device ptrs*/);
+
+// ---- kernels_mf.hip -----------------------------------------------------------------------------
+struct MfArgs { int dim, k_u; BoxDev box; const double *Ke; const uint8_t *mask; const double *diag_local; };
+void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained);
+void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
+
+}  // namespace poro

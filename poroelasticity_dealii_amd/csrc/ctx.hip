@@ -1,0 +1,611 @@
+// Host logic of the HIP back end: context set-up (setup_dofs of the three solvers), the device-resident
+// PCG loop, slab-partition communication (RCCL over xGMI, or host-staged callbacks for tests) and the
+// extern "C" entry points of include/poroel_hip.h.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include "common.hpp"
+
+using namespace poro;
+
+namespace {
+
+thread_local std::string g_err;
+
+int ipow(int b, int e) { int r = 1; while (e--) r *= b; return r; }
+
+template <class F> void parallel_for(int64_t n, F &&f) {
+  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 32) nt = 32;
+  if (n < 20000 || nt == 1) { f(0, n); return; }
+  std::vector<std::thread> th; const int64_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) { const int64_t b = t * chunk, e = std::min<int64_t>(n, b + chunk); if (b < e) th.emplace_back([=, &f] { f(b, e); }); }
+  for (auto &t : th) t.join();
+}
+
+// DoFTools::make_sparsity_pattern(keep_constrained_dofs = true): every dof couples with all dofs of its cells
+void build_pattern(int64_t n, int64_t n_cells, int dpc, const int32_t *cell_dofs, std::vector<int64_t> &rp, std::vector<int32_t> &col, std::vector<int64_t> &diag) {
+  std::vector<int64_t> cnt(n + 1, 0);
+  for (int64_t i = 0; i < n_cells * dpc; ++i) cnt[cell_dofs[i] + 1]++;
+  for (int64_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+  std::vector<int32_t> adj(cnt[n]);
+  { std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int64_t c = 0; c < n_cells; ++c) for (int i = 0; i < dpc; ++i) adj[pos[cell_dofs[c * dpc + i]]++] = (int32_t)c; }
+  rp.assign(n + 1, 0);
+  auto row_cols = [&](int64_t r, std::vector<int32_t> &row) {
+    row.clear();
+    for (int64_t a = cnt[r]; a < cnt[r + 1]; ++a) { const int32_t *cd = cell_dofs + (int64_t)adj[a] * dpc; row.insert(row.end(), cd, cd + dpc); }
+    std::sort(row.begin(), row.end()); row.erase(std::unique(row.begin(), row.end()), row.end());
+  };
+  parallel_for(n, [&](int64_t b, int64_t e) { std::vector<int32_t> row; for (int64_t r = b; r < e; ++r) { row_cols(r, row); rp[r + 1] = (int64_t)row.size(); } });
+  for (int64_t r = 0; r < n; ++r) rp[r + 1] += rp[r];
+  col.resize(rp[n]); diag.resize(n);
+  parallel_for(n, [&](int64_t b, int64_t e) {
+    std::vector<int32_t> row;
+    for (int64_t r = b; r < e; ++r) {
+      row_cols(r, row); std::copy(row.begin(), row.end(), col.begin() + rp[r]);
+      diag[r] = rp[r] + (std::lower_bound(row.begin(), row.end(), (int32_t)r) - row.begin());
+    }
+  });
+}
+
+void upload_csr(CsrDev &A, int64_t n, const std::vector<int64_t> &rp, const std::vector<int32_t> &col, const std::vector<int64_t> &diag) {
+  A.n = n; A.nnz = (int64_t)col.size(); A.rp.upload(rp); A.col.upload(col); A.diag_pos.upload(diag);
+  const double avg = n ? (double)A.nnz / n : 1; int L = 2;
+  while (L < 64 && L * 4 < avg) L *= 2;
+  A.lanes_per_row = L;
+}
+
+// greedy colouring: cells of one colour share no vertex, hence no dof
+void colour_cells(int64_t n_cells, int64_t n_vertices, int nv, const int32_t *cv, std::vector<int32_t> &cells_sorted, std::vector<int64_t> &off) {
+  std::vector<int64_t> vp(n_vertices + 1, 0);
+  for (int64_t i = 0; i < n_cells * nv; ++i) vp[cv[i] + 1]++;
+  for (int64_t i = 0; i < n_vertices; ++i) vp[i + 1] += vp[i];
+  std::vector<int32_t> vc(vp[n_vertices]);
+  { std::vector<int64_t> pos(vp.begin(), vp.end() - 1); for (int64_t c = 0; c < n_cells; ++c) for (int v = 0; v < nv; ++v) vc[pos[cv[c * nv + v]]++] = (int32_t)c; }
+  std::vector<int> colour(n_cells, -1); int ncol = 0;
+  for (int64_t c = 0; c < n_cells; ++c) {
+    uint64_t used = 0;
+    for (int v = 0; v < nv; ++v) { const int32_t vx = cv[c * nv + v]; for (int64_t a = vp[vx]; a < vp[vx + 1]; ++a) { const int k = colour[vc[a]]; if (k >= 0) used |= (1ull << k); } }
+    int k = 0; while (used & (1ull << k)) ++k;
+    if (k >= 63) throw Error("colouring needs more than 63 colours");
+    colour[c] = k; ncol = std::max(ncol, k + 1);
+  }
+  off.assign(ncol + 1, 0);
+  for (int64_t c = 0; c < n_cells; ++c) off[colour[c] + 1]++;
+  for (int k = 0; k < ncol; ++k) off[k + 1] += off[k];
+  cells_sorted.resize(n_cells);
+  { std::vector<int64_t> pos(off.begin(), off.end() - 1); for (int64_t c = 0; c < n_cells; ++c) cells_sorted[pos[colour[c]]++] = (int32_t)c; }
+}
+
+// ---- RCCL, resolved at run time so single-GPU use has no dependency on it ---------------------------------------
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  void load() {
+    if (lib) return;
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) throw Error(std::string("cannot load librccl: ") + dlerror());
+    auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) throw Error(std::string("librccl lacks ") + n); return p; };
+    GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId"); CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy"); AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+    Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv"); GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd"); GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+  }
+} g_rccl;
+#define PORO_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) throw Error(std::string(#x) + " -> " + g_rccl.GetErrorString(r_)); } while (0)
+
+// ---- timing -----------------------------------------------------------------------------------------------------
+struct Timed {
+  poro_ctx *c; Timer *t = nullptr; hipEvent_t a = nullptr, b = nullptr;
+  Timed(poro_ctx *c_, const char *name) : c(c_) {
+    if (!c->timing) return;
+    t = &c->timers[name];
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream);
+  }
+  ~Timed() { if (!t) return; (void)hipEventRecord(b, c->stream); t->pending.emplace_back(a, b); t->launches++; }
+};
+void timers_collect(poro_ctx *c) {
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &kv : c->timers) {
+    for (auto &p : kv.second.pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.first, p.second); kv.second.seconds += ms * 1e-3; (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    kv.second.pending.clear();
+  }
+}
+
+// ---- communication: sum the neighbour's partial rows on the shared node planes; all-reduce scalars -------------------
+void exchange_add(poro_ctx *c, double *v, int64_t n, int64_t plane) {
+  Comm &cm = c->comm;
+  if (!cm.multi()) return;
+  Timed tm(c, "halo_exchange");
+  if (cm.recv_lo.n < (size_t)plane) { cm.recv_lo.alloc(plane); cm.recv_hi.alloc(plane); }
+  if (cm.nccl_comm) {
+    ncclComm_t comm = (ncclComm_t)cm.nccl_comm;
+    PORO_NCCL(g_rccl.GroupStart());
+    if (cm.part.has_upper) { PORO_NCCL(g_rccl.Send(v + n - plane, plane, ncclFloat64, cm.part.rank + 1, comm, c->stream)); PORO_NCCL(g_rccl.Recv(cm.recv_hi.p, plane, ncclFloat64, cm.part.rank + 1, comm, c->stream)); }
+    if (cm.part.has_lower) { PORO_NCCL(g_rccl.Send(v, plane, ncclFloat64, cm.part.rank - 1, comm, c->stream)); PORO_NCCL(g_rccl.Recv(cm.recv_lo.p, plane, ncclFloat64, cm.part.rank - 1, comm, c->stream)); }
+    PORO_NCCL(g_rccl.GroupEnd());
+  } else if (cm.sr) {
+    cm.hsend.resize(plane); cm.hrecv.resize(plane);
+    auto one = [&](double *dev_send, double *dev_recv, int peer) {
+      PORO_HIP(hipMemcpyAsync(cm.hsend.data(), dev_send, plane * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      PORO_HIP(hipStreamSynchronize(c->stream));
+      cm.sr(cm.hsend.data(), cm.hrecv.data(), plane, peer, cm.user);
+      PORO_HIP(hipMemcpyAsync(dev_recv, cm.hrecv.data(), plane * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      PORO_HIP(hipStreamSynchronize(c->stream));
+    };
+    if (cm.part.has_upper) one(v + n - plane, cm.recv_hi.p, cm.part.rank + 1);
+    if (cm.part.has_lower) one(v, cm.recv_lo.p, cm.part.rank - 1);
+  } else throw Error("partitioned context without a communicator (call poro_ctx_comm_init_* first)");
+  if (cm.part.has_upper) la_add_range(c->stream, v + n - plane, cm.recv_hi.p, plane);
+  if (cm.part.has_lower) la_add_range(c->stream, v, cm.recv_lo.p, plane);
+}
+void allreduce_sum(poro_ctx *c, double *dev, int n) {
+  Comm &cm = c->comm;
+  if (!cm.multi()) return;
+  Timed tm(c, "allreduce");
+  if (cm.nccl_comm) PORO_NCCL(g_rccl.AllReduce(dev, dev, n, ncclFloat64, ncclSum, (ncclComm_t)cm.nccl_comm, c->stream));
+  else if (cm.ar) {
+    double h[kScalarSlots];
+    PORO_HIP(hipMemcpyAsync(h, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+    cm.ar(h, n, cm.user);
+    PORO_HIP(hipMemcpyAsync(dev, h, n * sizeof(double), hipMemcpyHostToDevice, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+  } else throw Error("partitioned context without a communicator");
+}
+int64_t owned(poro_ctx *c, int64_t n, int64_t plane) { return (c->comm.multi() && c->comm.part.has_upper) ? n - plane : n; }
+
+AsmArgs asm_args(poro_ctx *c) {
+  AsmArgs a{};
+  a.dim = c->dim; a.k_u = c->k_u; a.ns_u = c->ns_u; a.ns_p = c->ns_p; a.nv = c->nv; a.dpc_u = c->dpc_u; a.fe = c->fe;
+  a.cell_dofs_u = c->cell_dofs_u.p; a.cell_dofs_p = c->cell_dofs_p.p; a.cell_X = c->cell_X.p; a.dir_mask = c->dir_mask.p; a.dir_val = c->dir_val.p; a.mat = c->mat;
+  return a;
+}
+MfArgs mf_args(poro_ctx *c) { MfArgs a{}; a.dim = c->dim; a.k_u = c->k_u; a.box = c->box; a.Ke = c->Ke.p; a.mask = c->dir_mask.p; a.diag_local = c->diag_u_local.p; return a; }
+
+double *vec(poro_ctx *c, int which) {
+  auto it = c->vec.find(which);
+  if (it == c->vec.end()) throw Error("unknown vector id " + std::to_string(which));
+  return it->second.p;
+}
+int64_t vec_len(poro_ctx *c, int which) { return (int64_t)c->vec.at(which).n; }
+bool is_u_vec(int which) { return which == PORO_VEC_U || which == PORO_VEC_RHS_U || which == PORO_VEC_DIAG_U; }
+
+void apply_A_u(poro_ctx *c, const double *x, double *y, int mode) {
+  {
+    Timed tm(c, mode == PORO_OP_MATRIX_FREE ? "apply_u_matrix_free" : "apply_u_csr");
+    if (mode == PORO_OP_MATRIX_FREE) mf_apply(c->stream, mf_args(c), x, y, true);
+    else la_csr_spmv(c->stream, c->Au, c->Au_val.p, x, y);
+  }
+  exchange_add(c, y, c->n_u, c->comm.part.plane_u);
+}
+
+// ---- PCG with device-side control: SolverCG<>::solve restated, Jacobi instead of SSOR ---------------
+int pcg(poro_ctx *c, const std::function<void(const double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
+        const double *diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
+  hipStream_t s = c->stream;
+  const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
+  const int64_t n_own = owned(c, n, plane);
+  double *part = c->partials.p, *red = c->red.p; PcgScalars *sc = c->scal.p;
+  hipEvent_t e0, e1; PORO_HIP(hipEventCreate(&e0)); PORO_HIP(hipEventCreate(&e1)); PORO_HIP(hipEventRecord(e0, s));
+  int64_t applies = 0;
+  // g = A x - b ; d = -P^-1 g ; gh = g.P^-1 g
+  apply(x, h); ++applies;
+  pcg_init_residual(s, g, h, b, n);
+  la_dot_partials(s, b, b, n_own, part);
+  pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
+  pcg_scalars_sum(s, part, 3, red);
+  allreduce_sum(c, red, 3);
+  pcg_scalars_start(s, sc, red, opts->abs_tol, opts->rel_tol, opts->max_iter);
+  PcgScalars hs{};
+  int batch = 4;
+  while (true) {
+    PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+    if (hs.done) break;
+    for (int k = 0; k < batch; ++k) {
+      apply(d, h); ++applies;
+      pcg_dot_dh(s, sc, d, h, n_own, part);
+      pcg_scalars_sum(s, part, 1, red); allreduce_sum(c, red, 1);
+      pcg_scalars_alpha(s, sc, red);
+      pcg_update_xg(s, sc, x, g, d, h, diag, prec, n, n_own, part);
+      pcg_scalars_sum(s, part, 2, red); allreduce_sum(c, red, 2);
+      pcg_scalars_beta(s, sc, red);
+      pcg_update_d(s, sc, d, g, diag, prec, n);
+    }
+    if (batch < 32) batch *= 2;
+  }
+  PORO_HIP(hipEventRecord(e1, s)); PORO_HIP(hipEventSynchronize(e1));
+  float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (info) { info->iterations = hs.it; info->converged = hs.converged; info->initial_residual = hs.res0; info->final_residual = hs.res; info->seconds = ms * 1e-3; info->operator_applications = applies; }
+  return hs.converged ? 0 : 1;
+}
+
+void setup(poro_ctx *c, const poro_desc *d) {
+  if (d->abi_version != PORO_ABI_VERSION) throw Error("poro_desc.abi_version mismatch");
+  if (d->dim != 2 && d->dim != 3) throw Error("dim must be 2 or 3");
+  if (d->degree_u != 1 && d->degree_u != 2) throw Error("degree_u must be 1 or 2");
+  if (d->degree_p != 1) throw Error("degree_p must be 1 (PoroElasticPressureSolver.h:20)");
+  c->dim = d->dim; c->k_u = d->degree_u; c->nv = 1 << d->dim; c->ns_u = ipow(c->k_u + 1, c->dim); c->ns_p = c->nv; c->dpc_u = c->ns_u * c->dim; c->dpc_p = c->ns_p;
+  c->n_cells = d->n_cells; c->n_u = d->n_dofs_u; c->n_p = d->n_dofs_p; c->mat = d->mat; c->comm.part = d->part;
+  if (c->comm.part.n_ranks < 1) { c->comm.part.n_ranks = 1; c->comm.part.rank = 0; }
+  const poro_fe_tables &f = d->fe;
+  if (f.nq_u != ipow(c->k_u + 1, c->dim) || f.nq_p != c->nv || f.ns_u != c->ns_u || f.ns_p != c->ns_p || f.nq_f != ipow(c->k_u + 1, c->dim - 1)) throw Error("poro_fe_tables sizes do not match dim / degree");
+  if (c->n_cells <= 0 || c->n_u <= 0 || c->n_p <= 0) throw Error("empty mesh");
+  for (int64_t i = 0; i < c->n_cells * c->dpc_u; ++i) if (d->cell_dofs_u[i] < 0 || d->cell_dofs_u[i] >= c->n_u) throw Error("cell_dofs_u out of range");
+  for (int64_t i = 0; i < c->n_cells * c->dpc_p; ++i) if (d->cell_dofs_p[i] < 0 || d->cell_dofs_p[i] >= c->n_p) throw Error("cell_dofs_p out of range");
+  for (int64_t i = 0; i < c->n_cells * c->nv; ++i) if (d->cell_vertices[i] < 0 || d->cell_vertices[i] >= d->n_vertices) throw Error("cell_vertices out of range");
+  if (c->operator_mode == PORO_OP_MATRIX_FREE) {
+    if (!d->box.enabled) throw Error("matrix-free operator needs a structured box mesh (poro_desc.box)");
+    // the lexicographic numbering the kernel assumes must be the caller's numbering
+    int64_t nn[3] = {1, 1, 1}; for (int k = 0; k < c->dim; ++k) nn[k] = (int64_t)c->k_u * d->box.n[k] + 1;
+    if (nn[0] * nn[1] * nn[2] * c->dim != c->n_u) throw Error("box does not match n_dofs_u");
+    const int n1 = c->k_u + 1;
+    const int64_t ncx = d->box.n[0], ncy = d->box.n[1];
+    for (int64_t cell : {(int64_t)0, c->n_cells / 2, c->n_cells - 1}) {
+      const int64_t ci = cell % ncx, cj = (cell / ncx) % ncy, ck = cell / (ncx * ncy);
+      for (int sidx = 0; sidx < c->ns_u; ++sidx) {
+        const int a = sidx % n1, b = (sidx / n1) % n1, cc = sidx / (n1 * n1);
+        const int64_t node = ((ck * c->k_u + cc) * nn[1] + (cj * c->k_u + b)) * nn[0] + (ci * c->k_u + a);
+        for (int k = 0; k < c->dim; ++k) if (d->cell_dofs_u[(cell * c->ns_u + sidx) * c->dim + k] != node * c->dim + k) throw Error("cell_dofs_u is not the lexicographic box numbering");
+      }
+    }
+  }
+  c->box.enabled = d->box.enabled;
+  for (int k = 0; k < 3; ++k) { c->box.n[k] = d->box.enabled && k < c->dim ? d->box.n[k] : 1; c->box.h[k] = d->box.h[k]; c->box.nn[k] = c->k_u * c->box.n[k] + 1; }
+
+  // tables -> one device buffer
+  std::vector<double> T; std::vector<size_t> off;
+  auto push = [&](const double *p, size_t n) { off.push_back(T.size()); T.insert(T.end(), p, p + n); };
+  const int dim = c->dim, nf = 2 * dim;
+  push(f.w_qu, f.nq_u); push(f.w_qp, f.nq_p); push(f.w_qf, f.nq_f); push(f.u_qu, (size_t)f.nq_u * f.ns_u); push(f.du_qu, (size_t)f.nq_u * f.ns_u * dim);
+  push(f.du_qp, (size_t)f.nq_p * f.ns_u * dim); push(f.q1_qu, (size_t)f.nq_u * f.ns_p); push(f.dq1_qu, (size_t)f.nq_u * f.ns_p * dim);
+  push(f.q1_qp, (size_t)f.nq_p * f.ns_p); push(f.dq1_qp, (size_t)f.nq_p * f.ns_p * dim); push(f.u_qf, (size_t)nf * f.nq_f * f.ns_u); push(f.dq1_qf, (size_t)nf * f.nq_f * f.ns_p * dim);
+  c->tables.upload(T);
+  const double *tb = c->tables.p;
+  c->fe = FeTablesDev{f.nq_u, f.nq_p, f.nq_f, f.ns_u, f.ns_p, tb + off[0], tb + off[1], tb + off[2], tb + off[3], tb + off[4], tb + off[5], tb + off[6], tb + off[7], tb + off[8], tb + off[9], tb + off[10], tb + off[11]};
+
+  c->cell_dofs_u.upload(d->cell_dofs_u, c->n_cells * c->dpc_u); c->cell_dofs_p.upload(d->cell_dofs_p, c->n_cells * c->dpc_p);
+  { std::vector<double> X((size_t)c->n_cells * c->nv * dim);
+    for (int64_t i = 0; i < c->n_cells * c->nv; ++i) for (int k = 0; k < dim; ++k) X[i * dim + k] = d->vertex_coords[(int64_t)d->cell_vertices[i] * dim + k];
+    c->cell_X.upload(X); }
+  { std::vector<int32_t> cells; colour_cells(c->n_cells, d->n_vertices, c->nv, d->cell_vertices, cells, c->color_off); c->color_cells.upload(cells); }
+  { std::vector<uint8_t> m(c->n_u, 0); std::vector<double> v(c->n_u, 0.0);
+    for (int64_t i = 0; i < d->n_dirichlet; ++i) { const int32_t dof = d->dirichlet_dof[i]; if (dof < 0 || dof >= c->n_u) throw Error("dirichlet_dof out of range"); m[dof] = 1; v[dof] = d->dirichlet_value[i]; }
+    c->dir_mask.upload(m); c->dir_val.upload(v);
+    c->h_dir_dof.assign(d->dirichlet_dof, d->dirichlet_dof + d->n_dirichlet); c->h_dir_val.assign(d->dirichlet_value, d->dirichlet_value + d->n_dirichlet); }
+  c->n_bfaces = d->n_bfaces; c->n_neumann = d->n_neumann;
+  if (d->n_bfaces) { c->bface_cell.upload(d->bface_cell, d->n_bfaces); c->bface_local.upload(d->bface_local, d->n_bfaces); c->bface_id.upload(d->bface_id, d->n_bfaces); }
+  if (d->n_neumann) { c->neu_label.upload(d->neumann_label, d->n_neumann); c->neu_comp.upload(d->neumann_component, d->n_neumann); c->neu_val.upload(d->neumann_value, d->n_neumann); }
+
+  // sparsity patterns (PoroElasticPressureSolver.h:80-94, PoroElasticDisplacementSolver.h:140-149)
+  { std::vector<int64_t> rp, diag; std::vector<int32_t> col; build_pattern(c->n_p, c->n_cells, c->dpc_p, d->cell_dofs_p, rp, col, diag); upload_csr(c->Ap, c->n_p, rp, col, diag); }
+  c->Mp.alloc(c->Ap.nnz); c->Kp.alloc(c->Ap.nnz); c->Jp.alloc(c->Ap.nnz);
+  if (c->operator_mode == PORO_OP_CSR) {
+    std::vector<int64_t> rp, diag; std::vector<int32_t> col; build_pattern(c->n_u, c->n_cells, c->dpc_u, d->cell_dofs_u, rp, col, diag); upload_csr(c->Au, c->n_u, rp, col, diag);
+    c->Au_val.alloc(c->Au.nnz);
+  } else c->Ke.alloc((size_t)c->dpc_u * c->dpc_u);
+
+  hipStream_t s = c->stream;
+  const int n_sym = dim * (dim + 1) / 2;
+  for (int id : {PORO_VEC_U, PORO_VEC_RHS_U, PORO_VEC_DIAG_U}) { c->vec[id].alloc(c->n_u); c->vec[id].zero(s); }
+  for (int id : {PORO_VEC_P, PORO_VEC_P_OLD, PORO_VEC_DP, PORO_VEC_RESIDUAL_P, PORO_VEC_EPSV, PORO_VEC_EPSV0, PORO_VEC_SOURCE_P}) { c->vec[id].alloc(c->n_p); c->vec[id].zero(s); }
+  for (int e = 0; e < n_sym; ++e) { c->vec[PORO_VEC_STRAIN0 + e].alloc(c->n_p); c->vec[PORO_VEC_STRAIN0 + e].zero(s); c->vec[PORO_VEC_PROJ_RHS0 + e].alloc(c->n_p); c->vec[PORO_VEC_PROJ_RHS0 + e].zero(s); }
+  for (DevBuf<double> *b : {&c->lift_u, &c->neumann_u, &c->diag_u_local, &c->wg_u, &c->wd_u, &c->wh_u}) { b->alloc(c->n_u); b->zero(s); }
+  for (DevBuf<double> *b : {&c->diag_J, &c->diag_M, &c->src_local, &c->wg_p, &c->wd_p, &c->wh_p, &c->tmp_p}) { b->alloc(c->n_p); b->zero(s); }
+  c->partials.alloc((size_t)4 * kMaxPartials); c->partials.zero(s); c->scal.alloc(1); c->scal.zero(s); c->red.alloc(kScalarSlots); c->red.zero(s);
+
+  // MatrixCreator::create_mass_matrix / create_laplace_matrix (:96-101) + the time-independent well integral (:142-147)
+  c->Mp.zero(s); c->Kp.zero(s); c->Jp.zero(s);
+  const AsmArgs a = asm_args(c);
+  for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
+    asm_p_matrices(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], c->Ap.rp.p, c->Ap.col.p, c->Mp.p, c->Kp.p, c->src_local.p);
+  PORO_HIP(hipStreamSynchronize(s));
+}
+
+void sync_source_vector(poro_ctx *c) {   // PORO_VEC_SOURCE_P = the assembled (rank-summed) well integral
+  la_copy(c->stream, vec(c, PORO_VEC_SOURCE_P), c->src_local.p, c->n_p);
+  exchange_add(c, vec(c, PORO_VEC_SOURCE_P), c->n_p, c->comm.part.plane_p);
+}
+
+template <class F> int guarded(F &&f) {
+  try { return f(); }
+  catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+}  // namespace
+
+// ======================================= extern "C" ================================================================
+extern "C" {
+
+const char *poro_last_error(void) { return g_err.c_str(); }
+int poro_abi_version(void) { return PORO_ABI_VERSION; }
+
+int poro_ctx_create(const poro_desc *desc, int device, int operator_mode, poro_ctx **out) {
+  return guarded([&] {
+    if (!desc || !out) throw Error("null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error("no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) throw Error("device index out of range");
+    PORO_HIP(hipSetDevice(device));
+    std::unique_ptr<poro_ctx> c(new poro_ctx());
+    c->device = device; c->operator_mode = operator_mode;
+    PORO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    setup(c.get(), desc);
+    *out = c.release();
+    return 0;
+  });
+}
+
+void poro_ctx_destroy(poro_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  timers_collect(c);
+  if (c->comm.nccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->comm.nccl_comm);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int poro_comm_unique_id(void *id128) {
+  return guarded([&] { g_rccl.load(); ncclUniqueId id; PORO_NCCL(g_rccl.GetUniqueId(&id)); static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId"); std::memcpy(id128, &id, 128); return 0; });
+}
+int poro_ctx_comm_init_rccl(poro_ctx *c, const void *id128) {
+  return guarded([&] {
+    g_rccl.load(); PORO_HIP(hipSetDevice(c->device));
+    ncclUniqueId id; std::memcpy(&id, id128, 128); ncclComm_t comm;
+    PORO_NCCL(g_rccl.CommInitRank(&comm, c->comm.part.n_ranks, id, c->comm.part.rank));
+    c->comm.nccl_comm = comm; return 0;
+  });
+}
+int poro_ctx_comm_init_callbacks(poro_ctx *c, poro_allreduce_fn ar, poro_sendrecv_fn sr, void *user) { c->comm.ar = ar; c->comm.sr = sr; c->comm.user = user; return 0; }
+
+int poro_vec_set(poro_ctx *c, int which, const double *host, int64_t n) {
+  return guarded([&] { PORO_HIP(hipSetDevice(c->device)); if (vec_len(c, which) != n) throw Error("vector length mismatch"); PORO_HIP(hipMemcpyAsync(vec(c, which), host, n * sizeof(double), hipMemcpyHostToDevice, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream)); return 0; });
+}
+int poro_vec_get(poro_ctx *c, int which, double *host, int64_t n) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device)); if (vec_len(c, which) != n) throw Error("vector length mismatch");
+    if (which == PORO_VEC_SOURCE_P) sync_source_vector(c);
+    if (which == PORO_VEC_DIAG_U) la_copy(c->stream, vec(c, which), c->diag_u.p ? c->diag_u.p : c->diag_u_local.p, n);
+    PORO_HIP(hipMemcpyAsync(host, vec(c, which), n * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream)); return 0;
+  });
+}
+int poro_vec_fill(poro_ctx *c, int which, double v) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); la_fill(c->stream, vec(c, which), v, vec_len(c, which)); return 0; }); }
+int poro_vec_copy(poro_ctx *c, int dst, int src) {
+  return guarded([&] { PORO_HIP(hipSetDevice(c->device)); if (vec_len(c, dst) != vec_len(c, src)) throw Error("vector length mismatch"); la_copy(c->stream, vec(c, dst), vec(c, src), vec_len(c, dst)); return 0; });
+}
+int poro_vec_axpy(poro_ctx *c, int y, double a, int x) {
+  return guarded([&] { PORO_HIP(hipSetDevice(c->device)); if (vec_len(c, y) != vec_len(c, x)) throw Error("vector length mismatch"); la_axpy(c->stream, vec(c, y), a, vec(c, x), vec_len(c, y)); return 0; });
+}
+int poro_vec_norm(poro_ctx *c, int which, double *l2, double *linf) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    const int64_t n = vec_len(c, which), plane = is_u_vec(which) ? c->comm.part.plane_u : c->comm.part.plane_p;
+    la_norm_partials(c->stream, vec(c, which), owned(c, n, plane), c->partials.p, c->partials.p + kMaxPartials);
+    la_reduce_finish(c->stream, c->partials.p, 2, c->red.p, 2);
+    allreduce_sum(c, c->red.p, 1);   // linf stays rank-local under a partition (reporting only, PoroelasticityFSS.h:387-389)
+    double h[2]; PORO_HIP(hipMemcpyAsync(h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+    if (l2) *l2 = std::sqrt(h[0]); if (linf) *linf = h[1]; return 0;
+  });
+}
+
+int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream; const AsmArgs a = asm_args(c);
+    if (rebuild_matrix || !c->matrix_built) {
+      Timed tm(c, "assemble_u_matrix");
+      c->lift_u.zero(s); c->neumann_u.zero(s);
+      if (c->operator_mode == PORO_OP_CSR) {
+        c->Au_val.zero(s);
+        for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
+          asm_u_matrix(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], c->Au.rp.p, c->Au.col.p, c->Au_val.p, c->lift_u.p);
+        la_csr_diag(s, c->Au, c->Au_val.p, c->diag_u_local.p);
+      } else {
+        asm_u_element_matrix(s, a, 0, c->Ke.p);
+        mf_diag(s, mf_args(c), c->diag_u_local.p);
+        // lifting: -(A_full g) on the free rows, through the unconstrained operator
+        mf_apply(s, mf_args(c), c->dir_val.p, c->wh_u.p, false);
+        la_fill(s, c->lift_u.p, 0.0, c->n_u); la_axpy(s, c->lift_u.p, -1.0, c->wh_u.p, c->n_u);
+      }
+      asm_u_neumann(s, a, c->n_bfaces, c->bface_cell.p, c->bface_local.p, c->bface_id.p, c->n_neumann, c->neu_label.p, c->neu_comp.p, c->neu_val.p, c->neumann_u.p);
+      if (!c->diag_u.p) c->diag_u.alloc(c->n_u);
+      la_copy(s, c->diag_u.p, c->diag_u_local.p, c->n_u);
+      exchange_add(c, c->diag_u.p, c->n_u, c->comm.part.plane_u);
+      c->matrix_built = true;
+    }
+    {
+      Timed tm(c, "assemble_u_rhs");
+      double *rhs = vec(c, PORO_VEC_RHS_U);
+      la_fill(s, rhs, 0.0, c->n_u);                                            // rhs_vector = 0 (:204)
+      for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
+        asm_u_rhs(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], vec(c, PORO_VEC_P), rhs);
+      la_rhs_u_finish(s, rhs, c->lift_u.p, c->neumann_u.p, c->dir_mask.p, c->n_u);
+    }
+    exchange_add(c, vec(c, PORO_VEC_RHS_U), c->n_u, c->comm.part.plane_u);
+    PORO_HIP(hipStreamSynchronize(s));
+    return 0;
+  });
+}
+
+int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *info) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
+    const int mode = c->operator_mode;
+    auto apply = [&](const double *x, double *y) { apply_A_u(c, x, y, mode); };
+    const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->diag_u.p, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
+    la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);   // constraints.distribute (:306)
+    PORO_HIP(hipStreamSynchronize(c->stream));
+    return rc;
+  });
+}
+
+int poro_pres_assemble_residual(poro_ctx *c, double dt, double *l2) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream; double *R = vec(c, PORO_VEC_RESIDUAL_P);
+    {
+      Timed tm(c, "pressure_residual");
+      la_pressure_tmp(s, c->tmp_p.p, vec(c, PORO_VEC_EPSV), vec(c, PORO_VEC_EPSV0), vec(c, PORO_VEC_P), vec(c, PORO_VEC_P_OLD), c->mat.biot_alpha / dt, 1. / c->mat.biot_M / dt, c->n_p);
+      la_csr_residual(s, c->Ap, c->Mp.p, c->Kp.p, c->mat.k_over_mu, c->tmp_p.p, vec(c, PORO_VEC_P), c->src_local.p, R);
+    }
+    exchange_add(c, R, c->n_p, c->comm.part.plane_p);
+    la_dot_partials(s, R, R, owned(c, c->n_p, c->comm.part.plane_p), c->partials.p);
+    la_reduce_finish(s, c->partials.p, 1, c->red.p, 0);
+    allreduce_sum(c, c->red.p, 1);
+    double h; PORO_HIP(hipMemcpyAsync(&h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+    if (l2) *l2 = std::sqrt(h);
+    return 0;
+  });
+}
+
+int poro_pres_assemble_jacobian(poro_ctx *c, double dt) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    Timed tm(c, "pressure_jacobian");
+    la_jacobian(c->stream, c->Jp.p, c->Mp.p, c->Kp.p, 1. / c->mat.biot_M / dt, c->mat.k_over_mu, c->Ap.nnz);
+    la_csr_diag(c->stream, c->Ap, c->Jp.p, c->diag_J.p);
+    exchange_add(c, c->diag_J.p, c->n_p, c->comm.part.plane_p);
+    c->jac_dt = dt;
+    return 0;
+  });
+}
+
+int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *info) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    if (c->jac_dt < 0) throw Error("pres_solve before pres_assemble_jacobian");
+    auto apply = [&](const double *x, double *y) { { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); } exchange_add(c, y, c->n_p, c->comm.part.plane_p); };
+    return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->diag_J.p, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+  });
+}
+
+int poro_pres_update_volumetric_strain(poro_ctx *c) {
+  return guarded([&] { PORO_HIP(hipSetDevice(c->device)); la_axpy(c->stream, vec(c, PORO_VEC_EPSV), c->mat.biot_alpha / c->mat.bulk_K, vec(c, PORO_VEC_DP), c->n_p); return 0; });
+}
+
+int poro_proj_assemble_matrix(poro_ctx *c) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    la_csr_diag(c->stream, c->Ap, c->Mp.p, c->diag_M.p);                       // projection_matrix = mass_matrix (StrainProjector.h:104)
+    exchange_add(c, c->diag_M.p, c->n_p, c->comm.part.plane_p);
+    c->projection_matrix_ready = true; return 0;
+  });
+}
+
+int poro_proj_assemble_rhs(poro_ctx *c, const int32_t *tensor_components, int32_t n_comp) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    const int dim = c->dim; if (n_comp < 0 || n_comp > 6) throw Error("n_comp out of range");
+    static const int m2[4] = {0, 1, 1, 2}, m3[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};   // TensorIndexer.h:24-31
+    double *rhs[6];
+    for (int k = 0; k < n_comp; ++k) {
+      if (tensor_components[k] < 0 || tensor_components[k] >= dim * dim) throw Error("tensor component out of range");
+      const int e = dim == 2 ? m2[tensor_components[k]] : m3[tensor_components[k]];
+      rhs[k] = vec(c, PORO_VEC_PROJ_RHS0 + e); la_fill(c->stream, rhs[k], 0.0, c->n_p);   // :146-147
+    }
+    {
+      Timed tm(c, "projection_rhs");
+      const AsmArgs a = asm_args(c);
+      for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
+        asm_proj_rhs(c->stream, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], vec(c, PORO_VEC_U), n_comp, tensor_components, rhs);
+    }
+    for (int k = 0; k < n_comp; ++k) exchange_add(c, rhs[k], c->n_p, c->comm.part.plane_p);
+    return 0;
+  });
+}
+
+int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, poro_solve_info *info) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    if (!c->projection_matrix_ready) throw Error("proj_solve before proj_assemble_matrix");
+    if (entry < 0 || entry >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
+    auto apply = [&](const double *x, double *y) { { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); } exchange_add(c, y, c->n_p, c->comm.part.plane_p); };
+    return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->diag_M.p, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+  });
+}
+
+int poro_get_volumetric_strain(poro_ctx *c) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    const int dim = c->dim; const double *sp[3];
+    static const int m2[4] = {0, 1, 1, 2}, m3[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    for (int a = 0; a < dim; ++a) sp[a] = vec(c, PORO_VEC_STRAIN0 + (dim == 2 ? m2[a * dim + a] : m3[a * dim + a]));
+    la_sum_strains(c->stream, vec(c, PORO_VEC_EPSV), sp, dim, c->n_p); return 0;
+  });
+}
+
+static void csr_of(poro_ctx *c, int which, CsrDev **A, double **val) {
+  switch (which) {
+    case PORO_MAT_A_U: if (c->operator_mode != PORO_OP_CSR) throw Error("A_u is matrix-free in this context"); *A = &c->Au; *val = c->Au_val.p; return;
+    case PORO_MAT_MASS_P: *A = &c->Ap; *val = c->Mp.p; return;
+    case PORO_MAT_LAPLACE_P: *A = &c->Ap; *val = c->Kp.p; return;
+    case PORO_MAT_JACOBIAN_P: *A = &c->Ap; *val = c->Jp.p; return;
+  }
+  throw Error("unknown matrix id");
+}
+int poro_export_csr_size(poro_ctx *c, int which, int64_t *n_rows, int64_t *nnz) {
+  return guarded([&] { CsrDev *A; double *v; csr_of(c, which, &A, &v); *n_rows = A->n; *nnz = A->nnz; return 0; });
+}
+int poro_export_csr(poro_ctx *c, int which, int64_t *row_ptr, int32_t *col, double *val) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device)); CsrDev *A; double *v; csr_of(c, which, &A, &v);
+    PORO_HIP(hipStreamSynchronize(c->stream));
+    PORO_HIP(hipMemcpy(row_ptr, A->rp.p, (A->n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost)); PORO_HIP(hipMemcpy(col, A->col.p, A->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    PORO_HIP(hipMemcpy(val, v, A->nnz * sizeof(double), hipMemcpyDeviceToHost)); return 0;
+  });
+}
+
+int poro_apply_operator(poro_ctx *c, int which, const double *x_host, double *y_host) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device)); hipStream_t s = c->stream;
+    const bool isu = which == PORO_MAT_A_U; const int64_t n = isu ? c->n_u : c->n_p;
+    DevBuf<double> x, y; x.upload(x_host, n); y.alloc(n);
+    if (isu) { if (!c->matrix_built) throw Error("apply A_u before disp_assemble_system"); apply_A_u(c, x.p, y.p, c->operator_mode); }
+    else { CsrDev *A; double *v; csr_of(c, which, &A, &v); la_csr_spmv(s, *A, v, x.p, y.p); exchange_add(c, y.p, n, c->comm.part.plane_p); }
+    PORO_HIP(hipMemcpyAsync(y_host, y.p, n * sizeof(double), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s)); return 0;
+  });
+}
+
+int poro_bench_operator(poro_ctx *c, int which, int operator_mode, int reps, double *seconds_per_apply) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device)); hipStream_t s = c->stream;
+    if (which != PORO_MAT_A_U) throw Error("bench_operator: only A_u");
+    if (!c->matrix_built) throw Error("bench_operator before disp_assemble_system");
+    if (operator_mode != c->operator_mode) throw Error("bench_operator: context was created with the other operator mode");
+    std::vector<double> hx(c->n_u); for (int64_t i = 0; i < c->n_u; ++i) hx[i] = std::sin(0.37 * (double)i);   // SURVEY 8d synthetic vector
+    DevBuf<double> x, y; x.upload(hx); y.alloc(c->n_u);
+    for (int k = 0; k < 3; ++k) apply_A_u(c, x.p, y.p, operator_mode);
+    hipEvent_t e0, e1; PORO_HIP(hipEventCreate(&e0)); PORO_HIP(hipEventCreate(&e1));
+    PORO_HIP(hipEventRecord(e0, s));
+    for (int k = 0; k < reps; ++k) apply_A_u(c, x.p, y.p, operator_mode);
+    PORO_HIP(hipEventRecord(e1, s)); PORO_HIP(hipEventSynchronize(e1));
+    float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *seconds_per_apply = ms * 1e-3 / reps; return 0;
+  });
+}
+
+int poro_timers_reset(poro_ctx *c) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); timers_collect(c); c->timers.clear(); c->timing = true; return 0; }); }
+int poro_timers_get(poro_ctx *c, const char *name, double *seconds, int64_t *launches) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device)); timers_collect(c);
+    auto it = c->timers.find(name);
+    if (seconds) *seconds = it == c->timers.end() ? 0.0 : it->second.seconds;
+    if (launches) *launches = it == c->timers.end() ? 0 : it->second.launches;
+    return 0;
+  });
+}
+
+}  // extern "C"

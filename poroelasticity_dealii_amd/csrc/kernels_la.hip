@@ -1,0 +1,313 @@
+// Sparse / dense linear-algebra kernels of the Krylov solves (gfx950, wave64):
+//   K-spmv  CSR fp64 SpMV (int32 columns, int64 row pointers), sub-wave row groups, shuffle reduction
+//   K-vec   fused PCG vector updates with deterministic two-stage reductions (no float atomics)
+//   K-res-p fused pressure residual, K-jac-p Jacobian value AXPY
+// All of these are HBM-bound streaming kernels: 8-16 B per lane coalesced accesses, grid-stride loops,
+// grids capped at kMaxPartials blocks for the reducing kernels so block partials fit one 8 KB slab.
+// Replaces deal.II SparseMatrix::vmult, Vector ops and SolverCG's inner loop
+// (PoroElasticDisplacementSolver.h:300-305, PoroElasticPressureSolver.h:122-153,162-167,176-179).
+#include "common.hpp"
+
+namespace poro {
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t n, int per_thread = 4) {
+  int64_t g = (n + (int64_t)kBlock * per_thread - 1) / ((int64_t)kBlock * per_thread);
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return (int)g;
+}
+inline int reduce_grid(int64_t n) {
+  int64_t g = (n + 2047) / 2048;
+  if (g < 1) g = 1;
+  if (g > kMaxPartials) g = kMaxPartials;
+  return (int)g;
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// block-wide sum in a fixed order (deterministic); result valid in thread 0
+__device__ inline double block_sum(double v, double *sh /*[4]*/) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+__device__ inline double block_max(double v, double *sh) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) r = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+  __syncthreads();
+  return r;
+}
+// block b writes its partial and zeroes the unused tail slots b+G, b+2G, ...
+__device__ inline void store_partial(double *partials, double v) {
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = v;
+    for (int t = blockIdx.x + gridDim.x; t < kMaxPartials; t += gridDim.x) partials[t] = 0.0;
+  }
+}
+
+__global__ void k_fill(double *x, double v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] = v;
+}
+__global__ void k_axpy(double *y, double a, const double *x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] += a * x[i];
+}
+__global__ void k_dot(const double *a, const double *b, int64_t n, double *partials) {
+  __shared__ double sh[4];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) s += a[i] * b[i];
+  s = block_sum(s, sh);
+  store_partial(partials, s);
+}
+__global__ void k_norm(const double *a, int64_t n, double *p2, double *pinf) {
+  __shared__ double sh[4];
+  double s = 0, m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) { const double v = a[i]; s += v * v; m = fmax(m, fabs(v)); }
+  s = block_sum(s, sh); m = block_max(m, sh);
+  store_partial(p2, s); store_partial(pinf, m);
+}
+// one block; set k is a max-reduction when bit k of max_mask is set, else a sum
+__global__ void k_reduce_finish(const double *partials, int n_sets, double *red, int max_mask) {
+  __shared__ double sh[4];
+  for (int k = 0; k < n_sets; ++k) {
+    const bool is_max = (max_mask >> k) & 1;
+    double v = 0;
+    for (int i = threadIdx.x; i < kMaxPartials; i += kBlock) { const double t = partials[k * kMaxPartials + i]; v = is_max ? fmax(v, t) : v + t; }
+    v = is_max ? block_max(v, sh) : block_sum(v, sh);
+    if (threadIdx.x == 0) red[k] = v;
+  }
+}
+
+template <int L> __global__ void k_spmv(int64_t n, const int64_t *__restrict__ rp, const int32_t *__restrict__ col, const double *__restrict__ val,
+                                        const double *__restrict__ x, double *__restrict__ y) {
+  const int lane = threadIdx.x % L;
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / L;
+  if (row >= n) return;   // whole L-groups leave together (kBlock % L == 0)
+  const int64_t b = rp[row], e = rp[row + 1];
+  double s = 0;
+  for (int64_t j = b + lane; j < e; j += L) s += val[j] * x[col[j]];
+#pragma unroll
+  for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, L);
+  if (lane == 0) y[row] = s;
+}
+template <int L> __global__ void k_residual(int64_t n, const int64_t *__restrict__ rp, const int32_t *__restrict__ col, const double *__restrict__ M,
+                                            const double *__restrict__ K, double kappa, const double *__restrict__ t, const double *__restrict__ p,
+                                            const double *__restrict__ src, double *__restrict__ R) {
+  const int lane = threadIdx.x % L;
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / L;
+  if (row >= n) return;
+  const int64_t b = rp[row], e = rp[row + 1];
+  double s1 = 0, s2 = 0;
+  for (int64_t j = b + lane; j < e; j += L) { const int32_t c = col[j]; s1 += M[j] * t[c]; s2 += K[j] * p[c]; }
+#pragma unroll
+  for (int off = L / 2; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, L); s2 += __shfl_xor(s2, off, L); }
+  // same association as the reference: residual = M t; tmp = (K p) * kappa; residual += tmp; += source; *= -1
+  if (lane == 0) R[row] = -((s1 + s2 * kappa) + src[row]);
+}
+__global__ void k_pressure_tmp(double *t, const double *ev, const double *ev0, const double *p, const double *po, double c1, double c2, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) t[i] = (ev[i] - ev0[i]) * c1 + (p[i] - po[i]) * c2;
+}
+__global__ void k_jacobian(double *J, const double *M, const double *K, double a, double kappa, int64_t nnz) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * kBlock) J[i] = M[i] * a + kappa * K[i];
+}
+__global__ void k_csr_diag(int64_t n, const int64_t *pos, const double *val, double *diag) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) diag[i] = val[pos[i]];
+}
+struct StrainPtrs { const double *p[3]; };
+__global__ void k_sum_strains(double *ev, StrainPtrs s, int n, int64_t len) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
+    double v = 0;
+    for (int k = 0; k < n; ++k) v += s.p[k][i];
+    ev[i] = v;
+  }
+}
+__global__ void k_set_constrained(double *x, const uint8_t *mask, const double *val, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) if (mask[i]) x[i] = val[i];
+}
+__global__ void k_rhs_u_finish(double *rhs, const double *lift, const double *neu, const uint8_t *mask, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) rhs[i] = mask[i] ? 0.0 : (rhs[i] + neu[i]) + lift[i];
+}
+
+// ---- PCG (deal.II SolverCG structure: g = A x - b, d = -P^-1 g) ----------------------------------
+__global__ void k_pcg_init_residual(double *g, const double *Ax, const double *b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) g[i] = Ax[i] - b[i];
+}
+__global__ void k_pcg_first_direction(double *d, const double *g, const double *diag, int prec, int64_t n, int64_t n_owned, double *partials) {
+  __shared__ double sh[4];
+  double gg = 0, gz = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double gi = g[i], z = prec ? gi / diag[i] : gi;
+    d[i] = -z;
+    if (i < n_owned) { gg += gi * gi; gz += gi * z; }
+  }
+  gg = block_sum(gg, sh); gz = block_sum(gz, sh);
+  store_partial(partials, gg); store_partial(partials + kMaxPartials, gz);
+}
+__global__ void k_pcg_dot_dh(const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials) {
+  __shared__ double sh[4];
+  if (sc->done) return;
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_owned; i += (int64_t)gridDim.x * kBlock) s += d[i] * h[i];
+  s = block_sum(s, sh);
+  store_partial(partials, s);
+}
+__global__ void k_pcg_update_xg(const PcgScalars *sc, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
+                                int64_t n_owned, double *partials) {
+  __shared__ double sh[4];
+  if (sc->done) return;
+  const double alpha = sc->alpha;
+  double gg = 0, gz = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double gi = g[i] + alpha * h[i];
+    g[i] = gi; x[i] += alpha * d[i];
+    if (i < n_owned) { const double z = prec ? gi / diag[i] : gi; gg += gi * gi; gz += gi * z; }
+  }
+  gg = block_sum(gg, sh); gz = block_sum(gz, sh);
+  store_partial(partials, gg); store_partial(partials + kMaxPartials, gz);
+}
+__global__ void k_pcg_update_d(const PcgScalars *sc, double *d, const double *g, const double *diag, int prec, int64_t n) {
+  if (sc->done) return;
+  const double beta = sc->beta;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double gi = g[i], z = prec ? gi / diag[i] : gi;
+    d[i] = beta * d[i] - z;
+  }
+}
+__global__ void k_scalars_sum(const PcgScalars *sc, const double *partials, int n_sets, double *red) {
+  __shared__ double sh[4];
+  if (sc && sc->done) return;
+  for (int k = 0; k < n_sets; ++k) {
+    double v = 0;
+    for (int i = threadIdx.x; i < kMaxPartials; i += kBlock) v += partials[k * kMaxPartials + i];
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) red[k] = v;
+  }
+}
+__global__ void k_scalars_start(PcgScalars *sc, const double *red, double abs_tol, double rel_tol, int max_iter) {
+  const double bb = red[0], gg = red[1], gz = red[2];
+  sc->tol = fmax(abs_tol, rel_tol * sqrt(bb));
+  sc->res0 = sc->res = sqrt(gg);
+  sc->gg = gg; sc->gz = gz; sc->gh = gz; sc->dh = 0; sc->alpha = 0; sc->beta = 0;
+  sc->it = 0; sc->max_iter = max_iter;
+  sc->converged = sc->res <= sc->tol; sc->done = sc->converged;
+}
+__global__ void k_scalars_alpha(PcgScalars *sc, const double *red) {
+  if (sc->done) return;
+  sc->dh = red[0]; sc->alpha = sc->gh / red[0];
+}
+__global__ void k_scalars_beta(PcgScalars *sc, const double *red) {
+  if (sc->done) return;
+  const double gg = red[0], gz = red[1];
+  sc->it += 1; sc->gg = gg; sc->gz = gz; sc->res = sqrt(gg);
+  if (sc->res <= sc->tol) { sc->done = 1; sc->converged = 1; return; }        // SolverControl::success
+  if (sc->it >= sc->max_iter) { sc->done = 1; sc->converged = 0; return; }    // SolverControl::failure -> NoConvergence
+  sc->beta = gz / sc->gh; sc->gh = gz;
+}
+
+template <class F> void dispatch_lanes(int L, F &&f) {
+  switch (L) {
+    case 2: f(std::integral_constant<int, 2>()); break;
+    case 4: f(std::integral_constant<int, 4>()); break;
+    case 8: f(std::integral_constant<int, 8>()); break;
+    case 16: f(std::integral_constant<int, 16>()); break;
+    case 32: f(std::integral_constant<int, 32>()); break;
+    default: f(std::integral_constant<int, 64>()); break;
+  }
+}
+
+}  // namespace
+
+void la_fill(hipStream_t s, double *x, double v, int64_t n) { if (n) hipLaunchKernelGGL(k_fill, grid_for(n), kBlock, 0, s, x, v, n); }
+void la_copy(hipStream_t s, double *y, const double *x, int64_t n) { if (n && y != x) PORO_HIP(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, s)); }
+void la_axpy(hipStream_t s, double *y, double a, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_axpy, grid_for(n), kBlock, 0, s, y, a, x, n); }
+void la_add_range(hipStream_t s, double *y, const double *x, int64_t n) { la_axpy(s, y, 1.0, x, n); }
+void la_dot_partials(hipStream_t s, const double *a, const double *b, int64_t n, double *partials) {
+  hipLaunchKernelGGL(k_dot, reduce_grid(n), kBlock, 0, s, a, b, n, partials);
+}
+void la_norm_partials(hipStream_t s, const double *a, int64_t n, double *p2, double *pinf) {
+  hipLaunchKernelGGL(k_norm, reduce_grid(n), kBlock, 0, s, a, n, p2, pinf);
+}
+void la_reduce_finish(hipStream_t s, const double *partials, int n_sets, double *red, int max_mask) {
+  hipLaunchKernelGGL(k_reduce_finish, 1, kBlock, 0, s, partials, n_sets, red, max_mask);
+}
+void la_csr_spmv(hipStream_t s, const CsrDev &A, const double *val, const double *x, double *y) {
+  if (!A.n) return;
+  dispatch_lanes(A.lanes_per_row, [&](auto L) {
+    constexpr int l = decltype(L)::value;
+    const int64_t grid = (A.n * l + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_spmv<l>, (unsigned)grid, kBlock, 0, s, A.n, A.rp.p, A.col.p, val, x, y);
+  });
+}
+void la_csr_residual(hipStream_t s, const CsrDev &A, const double *M, const double *K, double kappa, const double *t, const double *p, const double *src,
+                     double *R) {
+  if (!A.n) return;
+  dispatch_lanes(A.lanes_per_row, [&](auto L) {
+    constexpr int l = decltype(L)::value;
+    const int64_t grid = (A.n * l + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_residual<l>, (unsigned)grid, kBlock, 0, s, A.n, A.rp.p, A.col.p, M, K, kappa, t, p, src, R);
+  });
+}
+void la_pressure_tmp(hipStream_t s, double *t, const double *ev, const double *ev0, const double *p, const double *po, double c1, double c2, int64_t n) {
+  hipLaunchKernelGGL(k_pressure_tmp, grid_for(n), kBlock, 0, s, t, ev, ev0, p, po, c1, c2, n);
+}
+void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, double a, double kappa, int64_t nnz) {
+  hipLaunchKernelGGL(k_jacobian, grid_for(nnz), kBlock, 0, s, J, M, K, a, kappa, nnz);
+}
+void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag) {
+  hipLaunchKernelGGL(k_csr_diag, grid_for(A.n), kBlock, 0, s, A.n, A.diag_pos.p, val, diag);
+}
+void la_sum_strains(hipStream_t s, double *ev, const double *const *strains, int n, int64_t len) {
+  StrainPtrs sp{}; for (int k = 0; k < n; ++k) sp.p[k] = strains[k];
+  hipLaunchKernelGGL(k_sum_strains, grid_for(len), kBlock, 0, s, ev, sp, n, len);
+}
+void la_set_constrained(hipStream_t s, double *x, const uint8_t *mask, const double *val, int64_t n) {
+  hipLaunchKernelGGL(k_set_constrained, grid_for(n), kBlock, 0, s, x, mask, val, n);
+}
+void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const double *neu, const uint8_t *mask, int64_t n) {
+  hipLaunchKernelGGL(k_rhs_u_finish, grid_for(n), kBlock, 0, s, rhs, lift, neu, mask, n);
+}
+void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, int64_t n) {
+  hipLaunchKernelGGL(k_pcg_init_residual, grid_for(n), kBlock, 0, s, g, Ax, b, n);
+}
+void pcg_first_direction(hipStream_t s, double *d, const double *g, const double *diag, int prec, int64_t n, int64_t n_owned, double *partials) {
+  hipLaunchKernelGGL(k_pcg_first_direction, reduce_grid(n), kBlock, 0, s, d, g, diag, prec, n, n_owned, partials);
+}
+void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials) {
+  hipLaunchKernelGGL(k_pcg_dot_dh, reduce_grid(n_owned), kBlock, 0, s, sc, d, h, n_owned, partials);
+}
+void pcg_update_xg(hipStream_t s, const PcgScalars *sc, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
+                   int64_t n_owned, double *partials) {
+  hipLaunchKernelGGL(k_pcg_update_xg, reduce_grid(n), kBlock, 0, s, sc, x, g, d, h, diag, prec, n, n_owned, partials);
+}
+void pcg_update_d(hipStream_t s, const PcgScalars *sc, double *d, const double *g, const double *diag, int prec, int64_t n) {
+  hipLaunchKernelGGL(k_pcg_update_d, grid_for(n), kBlock, 0, s, sc, d, g, diag, prec, n);
+}
+void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red) {
+  hipLaunchKernelGGL(k_scalars_sum, 1, kBlock, 0, s, (const PcgScalars *)nullptr, partials, n_sets, red);
+}
+void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red, double abs_tol, double rel_tol, int max_iter) {
+  hipLaunchKernelGGL(k_scalars_start, 1, 1, 0, s, sc, red, abs_tol, rel_tol, max_iter);
+}
+void pcg_scalars_alpha(hipStream_t s, PcgScalars *sc, const double *red) { hipLaunchKernelGGL(k_scalars_alpha, 1, 1, 0, s, sc, red); }
+void pcg_scalars_beta(hipStream_t s, PcgScalars *sc, const double *red) { hipLaunchKernelGGL(k_scalars_beta, 1, 1, 0, s, sc, red); }
+
+}  // namespace poro

@@ -1,0 +1,108 @@
+// C entry points of the host layer (mesh / DoF / FE-table provider, parameter file front end and the
+// run() driver), so tests and bench.py can reach the C++ host code through ctypes.
+#include <cstring>
+#include <string>
+#include "input_data.hpp"
+#include "mesh.hpp"
+#include "problem.hpp"
+
+using namespace poro_host;
+
+namespace {
+thread_local std::string g_err;
+void fill_bc(BoundaryConditions &bc, int n_dir, const int32_t *dl, const int32_t *dc, const double *dv,
+             int n_neu, const int32_t *nl, const int32_t *nc, const double *nv) {
+  bc.dirichlet_labels.assign(dl, dl + n_dir); bc.dirichlet_components.assign(dc, dc + n_dir); bc.dirichlet_values.assign(dv, dv + n_dir);
+  bc.neumann_labels.assign(nl, nl + n_neu); bc.neumann_components.assign(nc, nc + n_neu); bc.neumann_values.assign(nv, nv + n_neu);
+}
+}  // namespace
+
+extern "C" {
+
+const char *poro_host_last_error() { return g_err.c_str(); }
+
+// structured box (or one slab of it): GridGenerator::hyper_rectangle(colorize) + uniform refinement
+void *poro_host_build_box(int dim, const int32_t *n, const double *size, int k_u, int rank, int n_ranks,
+                          int n_dir, const int32_t *dl, const int32_t *dc, const double *dv,
+                          int n_neu, const int32_t *nl, const int32_t *nc, const double *nv, const poro_material *mat) {
+  try {
+    auto *P = new ProblemData();
+    fill_bc(P->bc, n_dir, dl, dc, dv, n_neu, nl, nc, nv);
+    P->mat = *mat;
+    int nn[3] = {n[0], n[1], dim == 3 ? n[2] : 1}; double sz[3] = {size[0], size[1], dim == 3 ? size[2] : 1};
+    build_box_problem(*P, dim, nn, sz, k_u, rank, n_ranks);
+    return P;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+
+// Gmsh 2.2 mesh (GridIn::read_msh, PoroelasticityFSS.h:438-445)
+void *poro_host_build_gmsh(const char *path, int k_u,
+                           int n_dir, const int32_t *dl, const int32_t *dc, const double *dv,
+                           int n_neu, const int32_t *nl, const int32_t *nc, const double *nv, const poro_material *mat) {
+  try {
+    auto *P = new ProblemData();
+    fill_bc(P->bc, n_dir, dl, dc, dv, n_neu, nl, nc, nv);
+    P->mat = *mat;
+    P->mesh = read_gmsh22(path);
+    P->finalize(k_u);
+    return P;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+
+const poro_desc *poro_host_desc(void *h) { return &static_cast<ProblemData *>(h)->d; }
+void poro_host_free(void *h) { delete static_cast<ProblemData *>(h); }
+
+// InputDataPoroel::read_input_file flattened for ctypes
+typedef struct poro_input_flat {
+  int32_t dim; double domain_size[3]; int32_t initial_refinement_level, max_refinement_level;
+  double youngs_modulus, poisson_ratio, biot_coef, perm, poro, visc, bulk_density, f_comp, r_well, flow_rate;
+  double p_init, time_step, t_max, fss_tol, pressure_tol; int32_t max_fss_iterations, max_pressure_iterations;
+  int32_t n_dirichlet, dirichlet_labels[16], dirichlet_components[16]; double dirichlet_values[16];
+  int32_t n_neumann, neumann_labels[16], neumann_components[16]; double neumann_values[16];
+  double lame_constant, shear_modulus, bulk_modulus, grain_bulk_modulus, n_modulus, m_modulus;
+  poro_material material;
+} poro_input_flat;
+
+int poro_host_read_input(const char *path /* NULL = declared defaults */, poro_input_flat *o) {
+  try {
+    input_data::InputDataPoroel in;
+    if (path) in.read_input_file(path);
+    std::memset(o, 0, sizeof(*o));
+    o->dim = in.dim;
+    for (size_t i = 0; i < in.domain_size.size() && i < 3; ++i) o->domain_size[i] = in.domain_size[i];
+    o->initial_refinement_level = in.initial_refinement_level; o->max_refinement_level = in.max_refinement_level;
+    o->youngs_modulus = in.youngs_modulus; o->poisson_ratio = in.poisson_ratio; o->biot_coef = in.biot_coef; o->perm = in.perm; o->poro = in.poro;
+    o->visc = in.visc; o->bulk_density = in.bulk_density; o->f_comp = in.f_comp; o->r_well = in.r_well; o->flow_rate = in.flow_rate;
+    o->p_init = in.p_init; o->time_step = in.time_step; o->t_max = in.t_max; o->fss_tol = in.fss_tol; o->pressure_tol = in.pressure_tol;
+    o->max_fss_iterations = in.max_fss_iterations; o->max_pressure_iterations = in.max_pressure_iterations;
+    if (in.displacement_boundary_labels.size() > 16 || in.stress_boundary_labels.size() > 16) throw std::runtime_error("more than 16 boundary conditions");
+    if (in.displacement_boundary_labels.size() != in.displacement_boundary_components.size() || in.displacement_boundary_labels.size() != in.displacement_boundary_values.size() ||
+        in.stress_boundary_labels.size() != in.stress_boundary_components.size() || in.stress_boundary_labels.size() != in.stress_boundary_values.size())
+      throw std::runtime_error("boundary label / component / value lists differ in length");
+    o->n_dirichlet = (int32_t)in.displacement_boundary_labels.size();
+    for (int i = 0; i < o->n_dirichlet; ++i) { o->dirichlet_labels[i] = in.displacement_boundary_labels[i]; o->dirichlet_components[i] = in.displacement_boundary_components[i]; o->dirichlet_values[i] = in.displacement_boundary_values[i]; }
+    o->n_neumann = (int32_t)in.stress_boundary_labels.size();
+    for (int i = 0; i < o->n_neumann; ++i) { o->neumann_labels[i] = in.stress_boundary_labels[i]; o->neumann_components[i] = in.stress_boundary_components[i]; o->neumann_values[i] = in.stress_boundary_values[i]; }
+    o->lame_constant = in.lame_constant; o->shear_modulus = in.shear_modulus; o->bulk_modulus = in.bulk_modulus;
+    o->grain_bulk_modulus = in.grain_bulk_modulus; o->n_modulus = in.n_modulus; o->m_modulus = in.m_modulus;
+    o->material = in.material();
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// PoroElasticProblem<dim>::run() on the HIP back end (problem.hpp).  trace layout = oracle_run's.
+int poro_host_run(void *problem_data, int device, int operator_mode, double p_init, double dt, int n_steps,
+                  double fss_tol, double pressure_tol, int max_fss, int max_pres,
+                  double abs_u, double rel_u, int max_it, double *trace, int max_rows, poro_ctx **ctx_out) {
+  try {
+    auto *P = static_cast<ProblemData *>(problem_data);
+    RunControls rc; rc.p_init = p_init; rc.time_step = dt; rc.n_steps = n_steps; rc.fss_tol = fss_tol; rc.pressure_tol = pressure_tol;
+    rc.max_fss_iterations = max_fss; rc.max_pressure_iterations = max_pres; rc.abs_tol_u = abs_u; rc.rel_tol_u = rel_u; rc.max_iter = max_it;
+    int rows = 0;
+    if (P->mesh.dim == 2) { PoroElasticProblem<2> prob(*P, device, operator_mode); rows = prob.run(rc, trace, max_rows); if (ctx_out) *ctx_out = prob.release(); }
+    else { PoroElasticProblem<3> prob(*P, device, operator_mode); rows = prob.run(rc, trace, max_rows); if (ctx_out) *ctx_out = prob.release(); }
+    return rows;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+// Host-side mirror of the reference's operator interface for the hot path: the same class and member
+// names, argument meaning and error behaviour as lib/include/PoroElasticDisplacementSolver.h,
+// PoroElasticPressureSolver.h, StrainProjector.h and the FSS loop of PoroelasticityFSS.h:294-415,
+// forwarding to the C-ABI of include/poroel_hip.h.  deal.II Vector<double> members become handles to
+// device-resident vectors; nothing here computes on the CPU.
+#pragma once
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/poroel_hip.h"
+#include "mesh.hpp"
+
+namespace poro_host {
+
+// analogue of dealii::SolverControl::NoConvergence (thrown by cg.solve, e.g. PoroElasticDisplacementSolver.h:305)
+struct NoConvergence : std::runtime_error {
+  int last_step; double last_residual;
+  NoConvergence(const std::string &who, int it, double r)
+      : std::runtime_error(who + ": iterative method did not converge in " + std::to_string(it) + " steps, residual " + std::to_string(r)),
+        last_step(it), last_residual(r) {}
+};
+
+inline void check(int rc, const char *what) {
+  if (rc < 0) throw std::runtime_error(std::string(what) + ": " + poro_last_error());
+}
+
+// stand-in for dealii::Vector<double> members that now live in HBM
+struct DeviceVector {
+  poro_ctx *ctx = nullptr; int id = -1;
+  DeviceVector &operator=(double v) { check(poro_vec_fill(ctx, id, v), "vec_fill"); return *this; }
+  DeviceVector &operator=(const DeviceVector &o) { if (o.id != id || o.ctx != ctx) check(poro_vec_copy(ctx, id, o.id), "vec_copy"); return *this; }
+  DeviceVector &operator+=(const DeviceVector &o) { check(poro_vec_axpy(ctx, id, 1.0, o.id), "vec_axpy"); return *this; }
+  double l2_norm() const { double a, b; check(poro_vec_norm(ctx, id, &a, &b), "vec_norm"); return a; }
+  double linfty_norm() const { double a, b; check(poro_vec_norm(ctx, id, &a, &b), "vec_norm"); return b; }
+  void get(std::vector<double> &h, int64_t n) const { h.resize(n); check(poro_vec_get(ctx, id, h.data(), n), "vec_get"); }
+};
+
+struct RunControls {
+  double p_init = 10e6, time_step = 60; int n_steps = 1;
+  double fss_tol = 1e-8, pressure_tol = 1e-8; int max_fss_iterations = 50, max_pressure_iterations = 50;
+  double abs_tol_u = 1e-12, rel_tol_u = 0.0; int max_iter = 1000;   // PoroElasticDisplacementSolver.h:298-299
+};
+
+}  // namespace poro_host
+
+namespace solvers {
+using poro_host::DeviceVector;
+
+template <int dim> class PoroElasticDisplacementSolver {
+ public:
+  DeviceVector solution;                                   // PoroElasticDisplacementSolver.h:47
+  poro_solver_opts control{1e-12, 0.0, 1000, PORO_PREC_JACOBI};   // :298-299 (SSOR(1.2) -> Jacobi on device)
+  poro_solve_info  last{};
+  explicit PoroElasticDisplacementSolver(poro_ctx *c) : ctx(c) { solution.ctx = c; solution.id = PORO_VEC_U; }
+  void setup_dofs() { rebuild_system_matrix = true; }      // :106-153 (pattern / constraints are built by poro_ctx_create)
+  // :155-291 — pressure_solution must be the pressure solver's `solution`
+  void assemble_system(DeviceVector &pressure_solution) {
+    if (pressure_solution.id != PORO_VEC_P) throw std::invalid_argument("assemble_system expects pressure_solver.solution");
+    poro_host::check(poro_disp_assemble_system(ctx, rebuild_system_matrix ? 1 : 0), "disp_assemble_system");
+    rebuild_system_matrix = false;                         // :290
+  }
+  void solve() {                                           // :294-307
+    const int rc = poro_disp_solve(ctx, &control, &last);
+    poro_host::check(rc, "disp_solve");
+    if (rc > 0) throw poro_host::NoConvergence("PoroElasticDisplacementSolver::solve", last.iterations, last.final_residual);
+  }
+ private:
+  poro_ctx *ctx; bool rebuild_system_matrix = true;        // :55
+};
+
+template <int dim> class PoroElasticPressureSolver {
+ public:
+  DeviceVector solution, solution_update, old_solution, residual;   // PoroElasticPressureSolver.h:38-40
+  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI};       // :175
+  poro_solve_info  last{};
+  explicit PoroElasticPressureSolver(poro_ctx *c) : ctx(c) {
+    solution.ctx = solution_update.ctx = old_solution.ctx = residual.ctx = c;
+    solution.id = PORO_VEC_P; solution_update.id = PORO_VEC_DP; old_solution.id = PORO_VEC_P_OLD; residual.id = PORO_VEC_RESIDUAL_P;
+  }
+  void setup_dofs() {}                                     // :68-111 (mass / Laplace matrices are built by poro_ctx_create)
+  void assemble_jacobian(double time_step) { poro_host::check(poro_pres_assemble_jacobian(ctx, time_step), "pres_assemble_jacobian"); }   // :158-169
+  // :113-155 — the strains must be the problem's volumetric_strain / initial_volumetric_strain
+  void assemble_residual(double time_step, DeviceVector &volumetric_strain, DeviceVector &initial_volumetric_strain) {
+    if (volumetric_strain.id != PORO_VEC_EPSV || initial_volumetric_strain.id != PORO_VEC_EPSV0) throw std::invalid_argument("assemble_residual expects the problem's strain vectors");
+    poro_host::check(poro_pres_assemble_residual(ctx, time_step, &residual_l2), "pres_assemble_residual");
+  }
+  void update_volumetric_strain(DeviceVector &volumetric_strain) {   // :187-194
+    if (volumetric_strain.id != PORO_VEC_EPSV) throw std::invalid_argument("update_volumetric_strain expects the problem's volumetric_strain");
+    poro_host::check(poro_pres_update_volumetric_strain(ctx), "pres_update_volumetric_strain");
+  }
+  void solve() {                                           // :172-185
+    const int rc = poro_pres_solve(ctx, &control, &last);
+    poro_host::check(rc, "pres_solve");
+    if (rc > 0) throw poro_host::NoConvergence("PoroElasticPressureSolver::solve", last.iterations, last.final_residual);
+  }
+  double residual_l2 = 0;   // residual.l2_norm() of the last assemble_residual, computed on device in the same pass
+ private:
+  poro_ctx *ctx;
+};
+}  // namespace solvers
+
+namespace projection {
+template <int dim> class StrainProjector {
+ public:
+  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI};       // StrainProjector.h:209
+  poro_solve_info  last{};
+  StrainProjector() {}
+  void set_solvers(poro_ctx *c) { ctx = c; }               // :73-79
+  void setup_dofs() {}                                     // :82-98
+  void assemble_projection_matrix() { poro_host::check(poro_proj_assemble_matrix(ctx), "proj_assemble_matrix"); }   // :101-106
+  void assemble_projection_rhs(std::vector<int> tensor_components) {   // :109-198
+    std::vector<int32_t> tc(tensor_components.begin(), tensor_components.end());
+    poro_host::check(poro_proj_assemble_rhs(ctx, tc.data(), (int32_t)tc.size()), "proj_assemble_rhs");
+  }
+  void solve_projection_system(int rhs_entry) {            // :201-232
+    const int rc = poro_proj_solve(ctx, rhs_entry, &control, &last);
+    poro_host::check(rc, "proj_solve");
+    if (rc > 0) throw poro_host::NoConvergence("StrainProjector::solve_projection_system", last.iterations, last.final_residual);
+  }
+ private:
+  poro_ctx *ctx = nullptr;
+};
+}  // namespace projection
+
+namespace indexing {
+// TensorIndexer.h:6-52
+template <int dim> class TensorIndexer {
+ public:
+  int entryIndex(int tensor_index) const {
+    static const int m2[4] = {0, 1, 1, 2}, m3[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    return dim == 2 ? m2[tensor_index] : m3[tensor_index];
+  }
+};
+}  // namespace indexing
+
+namespace poro_host {
+
+// PoroElasticProblem<dim> (PoroelasticityFSS.h:42-90): owns the context and reproduces run()'s call sequence
+// (:294-415) with mesh creation, AMR (:333-340) and output (:409-411) removed.
+template <int dim> class PoroElasticProblem {
+  poro_ctx *ctx;   // declared first: the solver members below are constructed from it
+ public:
+  PoroElasticProblem(ProblemData &P, int device, int operator_mode) : ctx(make_ctx(P, device, operator_mode)), pressure_solver(ctx), displacement_solver(ctx) {
+    volumetric_strain.ctx = initial_volumetric_strain.ctx = ctx;
+    volumetric_strain.id = PORO_VEC_EPSV; initial_volumetric_strain.id = PORO_VEC_EPSV0;
+    if (dim == 2) strain_tensor_volumetric_components = {0, 3}; else strain_tensor_volumetric_components = {0, 4, 8};   // :104-110
+  }
+  ~PoroElasticProblem() { if (ctx) poro_ctx_destroy(ctx); }
+  poro_ctx *context() { return ctx; }
+  poro_ctx *release() { poro_ctx *c = ctx; ctx = nullptr; return c; }
+
+  void setup_dofs() {                                      // :131-151
+    pressure_solver.setup_dofs(); displacement_solver.setup_dofs();
+    strain_projector.set_solvers(ctx); strain_projector.setup_dofs();
+  }
+  void get_normal_strain_components() {                    // :153-164
+    strain_projector.assemble_projection_rhs(strain_tensor_volumetric_components);
+    for (const auto &comp : strain_tensor_volumetric_components) strain_projector.solve_projection_system(tensor_indexer.entryIndex(comp));
+  }
+  void get_volumetric_strain() { check(poro_get_volumetric_strain(ctx), "get_volumetric_strain"); }   // :179-186
+
+  // trace rows: [step, fss_iteration, pressure_iterations, inner pressure error, |p|_inf, error after displacement, u CG its, p CG its]
+  int run(const RunControls &rc, double *trace, int max_rows) {
+    int rows = 0;
+    displacement_solver.control.abs_tol = rc.abs_tol_u; displacement_solver.control.rel_tol = rc.rel_tol_u;
+    displacement_solver.control.max_iter = pressure_solver.control.max_iter = strain_projector.control.max_iter = rc.max_iter;
+    setup_dofs();                                          // :308
+    pressure_solver.solution = rc.p_init;                  // :311
+    displacement_solver.assemble_system(pressure_solver.solution);   // :312
+    displacement_solver.solve();                           // :313
+    strain_projector.assemble_projection_matrix();         // :314
+    get_normal_strain_components();                        // :315
+    get_volumetric_strain();                               // :316
+    initial_volumetric_strain = volumetric_strain;         // :317
+    if (rows < max_rows) { double *r = trace + 8 * rows++; for (int i = 0; i < 8; ++i) r[i] = 0; r[6] = displacement_solver.last.iterations; }
+    double pressure_error;
+    for (int time_step_number = 1; time_step_number <= rc.n_steps; ++time_step_number) {   // :327-329
+      pressure_solver.old_solution = pressure_solver.solution;   // :342
+      pressure_error = rc.pressure_tol * 2; int fss_iteration = 0;   // :345-346
+      while (fss_iteration < rc.max_fss_iterations && pressure_error > rc.fss_tol) {   // :347-348
+        fss_iteration++;
+        int pressure_iteration = 0, pcg = 0; double inner = 0;
+        pressure_solver.solution_update = 0.0;             // :356
+        while (pressure_iteration < rc.max_pressure_iterations) {   // :358
+          pressure_iteration++;
+          pressure_solver.update_volumetric_strain(volumetric_strain);   // :360
+          pressure_solver.assemble_residual(rc.time_step, volumetric_strain, initial_volumetric_strain);   // :361-363
+          pressure_error = pressure_solver.residual_l2;    // :364
+          inner = pressure_error;
+          if (pressure_error < rc.pressure_tol) break;     // :366-371
+          pressure_solver.assemble_jacobian(rc.time_step); // :377
+          pressure_solver.solve(); pcg += pressure_solver.last.iterations;   // :378
+          pressure_solver.solution += pressure_solver.solution_update;   // :379
+        }
+        const double pinf = pressure_solver.solution.linfty_norm();   // :387-389
+        displacement_solver.assemble_system(pressure_solver.solution);   // :395
+        displacement_solver.solve();                       // :396
+        get_normal_strain_components();                    // :398  (get_volumetric_strain() stays commented out, :399)
+        pressure_solver.assemble_residual(rc.time_step, volumetric_strain, initial_volumetric_strain);   // :402-404
+        pressure_error = pressure_solver.residual_l2;      // :405
+        if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = time_step_number; r[1] = fss_iteration; r[2] = pressure_iteration - 1; r[3] = inner; r[4] = pinf; r[5] = pressure_error; r[6] = displacement_solver.last.iterations; r[7] = pcg; }
+      }
+    }
+    return rows;
+  }
+
+  solvers::PoroElasticPressureSolver<dim>     pressure_solver;     // :77
+  solvers::PoroElasticDisplacementSolver<dim> displacement_solver; // :78
+  projection::StrainProjector<dim>            strain_projector;    // :79
+  indexing::TensorIndexer<dim>                tensor_indexer;      // :81
+  DeviceVector volumetric_strain, initial_volumetric_strain;       // :83
+  std::vector<int> strain_tensor_volumetric_components;            // :86
+
+ private:
+  static poro_ctx *make_ctx(ProblemData &P, int device, int operator_mode) {
+    poro_ctx *c = nullptr;
+    check(poro_ctx_create(&P.d, device, operator_mode, &c), "poro_ctx_create");
+    return c;
+  }
+};
+
+}  // namespace poro_host

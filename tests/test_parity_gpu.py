@@ -1,0 +1,213 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on the same inputs — SURVEY 8c K8.
+Tolerances (fp64, stated per check): assembled values 1e-13 relative to the matrix max (summation order
+differs), residual / rhs vectors 1e-12 relative, converged solutions 1e-8 relative in l2 (both sides solve to
+a recursive residual; the oracle with the reference's SSOR-CG, the device with Jacobi-CG)."""
+import numpy as np
+import pytest
+
+import poroelasticity_dealii_amd as pk
+import oracle_py
+from common import BC_2D, BC_3D, DOMAIN_MSH, INPUT_DATA, REF, box_problem, csr_to_scipy, host_material, material, node_coords_box
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(2, 8, 1), (2, 8, 2), (2, (7, 5), 2), (3, 3, 1), (3, 3, 2), (3, (4, 2, 3), 2)]
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def rel2(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def synth(n, k=0.37):
+    return np.sin(k * np.arange(n))
+
+
+@pytest.fixture(params=CASES, ids=lambda c: f"{c[0]}d-n{c[1]}-Q{c[2]}")
+def pair(request):
+    dim, n, deg = request.param
+    P = box_problem(dim, n, deg)
+    O = oracle_py.Oracle(P, hoisted=True)
+    G = pk.Context(P, 0, pk.OP_CSR)
+    yield P, O, G
+    G.close(); O.close(); P.close()
+
+
+def test_pressure_matrices_and_source(pair):
+    P, O, G = pair
+    for which in (pk.MAT_MASS_P, pk.MAT_LAPLACE_P):
+        rp, col, val = G.export_csr(which); rp0, col0, val0 = O.export_csr(which)
+        assert np.array_equal(rp, rp0) and np.array_equal(col, col0)
+        assert np.abs(val - val0).max() <= 1e-13 * np.abs(val0).max()
+    O.fill(pk.VEC_P, 1.0); O.pres_assemble_residual(60.0)
+    assert rel(G.get(pk.VEC_SOURCE_P), O.get(pk.VEC_SOURCE_P)) <= 1e-13
+
+
+def test_displacement_matrix_and_rhs(pair):
+    P, O, G = pair
+    p = 10e6 * (1 + 0.1 * synth(G.n_p))
+    O.set(pk.VEC_P, p); G.set(pk.VEC_P, p)
+    O.disp_assemble_system(True); G.disp_assemble_system(True)
+    rp, col, val = G.export_csr(pk.MAT_A_U); rp0, col0, val0 = O.export_csr(pk.MAT_A_U)
+    assert np.array_equal(rp, rp0) and np.array_equal(col, col0)
+    assert np.abs(val - val0).max() <= 1e-13 * np.abs(val0).max()
+    A = csr_to_scipy(rp, col, val)
+    assert abs(A - A.T).max() <= 1e-13 * np.abs(val).max()
+    assert rel(G.get(pk.VEC_RHS_U), O.get(pk.VEC_RHS_U)) <= 1e-12
+    # rhs-only path (rebuild_system_matrix == false, PoroElasticDisplacementSolver.h:284-286) with a new pressure
+    p2 = p * 1.01
+    O.set(pk.VEC_P, p2); G.set(pk.VEC_P, p2)
+    O.disp_assemble_system(False); G.disp_assemble_system(False)
+    assert rel(G.get(pk.VEC_RHS_U), O.get(pk.VEC_RHS_U)) <= 1e-12
+    x = synth(G.n_u, 0.11)
+    assert rel(G.apply(pk.MAT_A_U, x), O.apply(pk.MAT_A_U, x)) <= 1e-13
+
+
+def test_matrix_free_operator_equals_assembled(pair):
+    P, O, G = pair
+    p = 10e6 * (1 + 0.1 * synth(G.n_p))
+    O.set(pk.VEC_P, p); O.disp_assemble_system(True)
+    F = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    try:
+        F.set(pk.VEC_P, p); F.disp_assemble_system(True)
+        x = synth(F.n_u, 0.11)
+        y, y0 = F.apply(pk.MAT_A_U, x), O.apply(pk.MAT_A_U, x)
+        assert rel(y, y0) <= 1e-12
+        assert rel(F.get(pk.VEC_RHS_U), O.get(pk.VEC_RHS_U)) <= 1e-12
+        rp, col, val = O.export_csr(pk.MAT_A_U)
+        assert rel(F.get(pk.VEC_DIAG_U), csr_to_scipy(rp, col, val).diagonal()) <= 1e-13
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("mode", [pk.OP_CSR, pk.OP_MATRIX_FREE], ids=["csr", "matrix_free"])
+def test_displacement_solve_and_projection(pair, mode):
+    P, O, _ = pair
+    G = pk.Context(P, 0, mode)
+    try:
+        p = 10e6 * (1 + 0.1 * synth(G.n_p))
+        O.set(pk.VEC_P, p); G.set(pk.VEC_P, p)
+        O.disp_assemble_system(True); G.disp_assemble_system(True)
+        rc0, i0 = O.disp_solve(abs_tol=1e-12, max_iter=1000)                      # the reference's SSOR(1.2)-CG
+        rc, i1 = G.disp_solve(abs_tol=1e-12, max_iter=5000)
+        assert rc0 == 0 and rc == 0, (i0.iterations, i1.iterations, i1.final_residual)
+        u, u0 = G.get(pk.VEC_U), O.get(pk.VEC_U)
+        assert rel2(u, u0) <= 1e-9
+        comps = [a * G.dim + a for a in range(G.dim)]
+        O.proj_assemble_matrix(); G.proj_assemble_matrix()
+        O.set(pk.VEC_U, u); O.proj_assemble_rhs(comps); G.proj_assemble_rhs(comps)
+        entries = [0, 2] if G.dim == 2 else [0, 3, 5]
+        for e in entries:
+            assert rel(G.get(pk.VEC_PROJ_RHS0 + e), O.get(pk.VEC_PROJ_RHS0 + e)) <= 1e-11
+            rc0, _ = O.proj_solve(e, rel_tol=1e-12); rc, _ = G.proj_solve(e, rel_tol=1e-12)
+            assert rc0 == 0 and rc == 0
+            assert rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
+        O.get_volumetric_strain(); G.get_volumetric_strain()
+        assert rel2(G.get(pk.VEC_EPSV), O.get(pk.VEC_EPSV)) <= 1e-9
+    finally:
+        G.close()
+
+
+def test_pressure_residual_jacobian_solve(pair):
+    P, O, G = pair
+    n = G.n_p
+    vals = {pk.VEC_P: 10e6 * (1 + 0.05 * synth(n)), pk.VEC_P_OLD: 10e6 * (1 + 0.05 * synth(n, 0.2)), pk.VEC_EPSV: -2e-6 * (1 + 0.3 * synth(n, 0.5)),
+            pk.VEC_EPSV0: -2e-6 * np.ones(n), pk.VEC_DP: 1e3 * synth(n, 0.7)}
+    for k, v in vals.items():
+        O.set(k, v); G.set(k, v)
+    O.pres_update_volumetric_strain(); G.pres_update_volumetric_strain()
+    assert rel(G.get(pk.VEC_EPSV), O.get(pk.VEC_EPSV)) <= 1e-15
+    r0, r1 = O.pres_assemble_residual(60.0), G.pres_assemble_residual(60.0)
+    assert abs(r1 - r0) <= 1e-12 * r0
+    assert rel(G.get(pk.VEC_RESIDUAL_P), O.get(pk.VEC_RESIDUAL_P)) <= 1e-12
+    O.pres_assemble_jacobian(60.0); G.pres_assemble_jacobian(60.0)
+    _, _, v1 = G.export_csr(pk.MAT_JACOBIAN_P); _, _, v0 = O.export_csr(pk.MAT_JACOBIAN_P)
+    assert np.abs(v1 - v0).max() <= 1e-13 * np.abs(v0).max()
+    rc0, _ = O.pres_solve(rel_tol=1e-13); rc, _ = G.pres_solve(rel_tol=1e-13)
+    assert rc0 == 0 and rc == 0
+    assert rel2(G.get(pk.VEC_DP), O.get(pk.VEC_DP)) <= 1e-9
+
+
+def test_patch_test_on_device():
+    """K2 on the device: uniform p, input.data BCs => u linear, eps_xx = eps_yy = -1e-6 exactly (Q2)."""
+    P = box_problem(2, 16, 2, mat=host_material())
+    G = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    try:
+        G.fill(pk.VEC_P, REF["p_init"]); G.disp_assemble_system(True)
+        rc, info = G.disp_solve(max_iter=5000)
+        assert rc == 0
+        X = node_coords_box(2, 16, 2); u = G.get(pk.VEC_U)
+        assert np.abs(u[0::2] + 1e-5 * (X[:, 0] + 5) / 10).max() <= 1e-17
+        assert np.abs(u[1::2] + 1e-5 * (X[:, 1] + 5) / 10).max() <= 1e-17
+        G.proj_assemble_matrix(); G.proj_assemble_rhs([0, 3])
+        for e in (0, 2):
+            assert G.proj_solve(e, rel_tol=1e-12)[0] == 0
+            assert np.abs(G.get(pk.VEC_STRAIN0 + e) + 1e-6).max() <= 1e-15
+    finally:
+        G.close(); P.close()
+
+
+@pytest.mark.parametrize("cfg", [("box", 2, 16, 2), ("box", 3, 4, 1), ("msh", 2, 0, 1), ("msh", 2, 0, 2)], ids=["ref-default-2dQ2", "3dQ1", "domain.msh-Q1", "domain.msh-Q2"])
+def test_run_trace_matches_oracle(cfg):
+    """K7/K8: the FSS time loop (PoroelasticityFSS.h:294-415) through the C++ host driver vs the oracle's restatement:
+    identical FSS / pressure iteration counts, matching residual norms and fields after 2 steps."""
+    kind, dim, n, deg = cfg
+    mat = host_material()
+    P = box_problem(dim, n, deg, mat=mat) if kind == "box" else pk.Problem.gmsh(DOMAIN_MSH, deg, mat, BC_2D)
+    O = oracle_py.Oracle(P)
+    try:
+        t0, _ = O.run(2, REF["p_init"], REF["dt"], max_it=1000)
+        assert O.noconvergence_count() == 0
+        t1, G = pk.run_problem(P, 2, REF["p_init"], REF["dt"], operator_mode=pk.OP_CSR, max_it=5000)
+        try:
+            assert t1.shape == t0.shape
+            assert np.array_equal(t1[:, :3], t0[:, :3])                      # step, fss iteration, pressure iterations
+            assert np.all(t1[1:, 3] < 1e-8) and np.all(t0[1:, 3] < 1e-8)      # inner residual under pressure_tol on both
+            assert np.allclose(t1[:, 4], t0[:, 4], rtol=1e-10)               # |p|_inf
+            assert rel2(G.get(pk.VEC_P), O.get(pk.VEC_P)) <= 1e-10
+            assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-8
+            assert rel2(G.get(pk.VEC_EPSV), O.get(pk.VEC_EPSV)) <= 1e-8
+        finally:
+            G.close()
+    finally:
+        O.close(); P.close()
+
+
+def test_neumann_traction():
+    """Neumann term (PoroElasticDisplacementSolver.h:249-277): traction on x-high / y-high instead of displacement."""
+    bc = [(0, 0, 0.0), (2, 1, 0.0)]
+    neu = [(1, 0, -2e6), (3, 1, -1e6)]
+    for dim, n, deg in ((2, 6, 2), (3, 3, 1)):
+        b = bc + ([(4, 2, 0.0)] if dim == 3 else [])
+        nm = neu + ([(5, 2, -3e6)] if dim == 3 else [])
+        P = box_problem(dim, n, deg, bc=b, neumann=nm)
+        O = oracle_py.Oracle(P, hoisted=True)
+        for mode in (pk.OP_CSR, pk.OP_MATRIX_FREE):
+            G = pk.Context(P, 0, mode)
+            O.fill(pk.VEC_P, 1e6); G.fill(pk.VEC_P, 1e6)
+            O.disp_assemble_system(True); G.disp_assemble_system(True)
+            assert rel(G.get(pk.VEC_RHS_U), O.get(pk.VEC_RHS_U)) <= 1e-12
+            G.close()
+        O.close(); P.close()
+
+
+def test_error_behaviour():
+    P = box_problem(2, 4, 2)
+    G = pk.Context(P, 0, pk.OP_CSR)
+    try:
+        with pytest.raises(RuntimeError):
+            G.disp_solve()                                  # solve before assemble
+        G.fill(pk.VEC_P, 10e6); G.disp_assemble_system(True)
+        rc, info = G.disp_solve(abs_tol=1e-30, max_iter=5)   # SolverControl::NoConvergence analogue
+        assert rc == 1 and info.iterations == 5 and info.converged == 0
+        with pytest.raises(RuntimeError):
+            G.set(pk.VEC_P, np.zeros(3))
+    finally:
+        G.close(); P.close()
+    Pm = pk.Problem.gmsh(DOMAIN_MSH, 2, material(), BC_2D)
+    with pytest.raises(RuntimeError):
+        pk.Context(Pm, 0, pk.OP_MATRIX_FREE)                # unstructured mesh cannot be matrix-free
+    Pm.close()
