@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the fixed-stress Biot hot path on MI355X.
+
+Metric (BASELINE.json): DoF-updates/sec in assemble + SpMV per fixed-stress iteration.
+One "step" = one time step of the reference's loop (PoroelasticityFSS.h:328-407) = one fixed-stress iteration
+(quirk Q1): pressure Newton loop, displacement RHS assembly + PCG solve with the matrix-free A_u, strain
+projection (RHS assembly + dim CG solves), residual check.  A DoF-update is one entry of a vector
+produced by an operator application y = A x or by an assembly pass; `value` = DoF-updates of the K timed steps
+(all ranks) / wall time of those steps, INCLUDING the Krylov vector work, reductions and host control.
+
+Workload: 3D Q2/Q1 uniform box, 72^3 cells per GPU (N_u = 9 145 875 at 1 GPU: BASELINE config "3D Q2/Q1 ~10M DoF");
+weak scaling: rank r owns a z-slab of 72 cell layers of a 72 x 72 x 72N box (edge 10 x 10 x 10N, same h).
+Input is synthetic in the sense of SURVEY 8d: the bundled input.data material / BC values on a generated mesh.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import poroelasticity_dealii_amd as pk  # noqa: E402
+
+INPUT = dict(E=1.4e10, nu=0.3, alpha=0.9, poro=0.3, f_comp=5.8e-10, perm_mD=10.0, visc=1e-3, r_well=1.0, flow_rate=1e-5, p_init=10e6, dt=60.0)   # input.data:13-40
+BC_3D = [(0, 0, 0.0), (1, 0, -1e-5), (2, 1, 0.0), (3, 1, -1e-5), (4, 2, 0.0), (5, 2, -1e-5)]   # input.data:14-16 + z faces
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def material():
+    # InputDataPoroel::compute_derived_parameters (InputDataPoroel.h:213-222) on the input.data values
+    E, nu, alpha, poro, cf = INPUT["E"], INPUT["nu"], INPUT["alpha"], INPUT["poro"], INPUT["f_comp"]
+    lam = E * nu / ((1. + nu) * (1. - 2. * nu)); G = 0.5 * E / (1 + nu); K = lam + 2. / 3. * G
+    Ks = K / (1. - alpha); N = Ks / (alpha - poro); M = (N / cf) / (N * poro + 1. / cf)
+    return pk.Material(lam, G, alpha, K, M, INPUT["perm_mD"] * 9.869233e-16 / INPUT["visc"], INPUT["r_well"], INPUT["flow_rate"])
+
+
+def dof_updates(w, n_u, n_p, dim):
+    """operator applications and assembly passes, each counted by the length of the vector it produces
+    (the pressure residual holds two SpMVs, mass and Laplace)."""
+    return (w["apply_u"] * n_u + w["asm_rhs_u"] * n_u + w["apply_p"] * n_p + w["residual_p"] * 2 * n_p + w["jacobian_p"] * n_p + w["proj_rhs"] * dim * n_p)
+
+
+def bytes_per_apply(dim, degree, n_u, n_cells, operator):
+    """algorithmic HBM bytes of one A_u application: matrix-free 16 N + 4 dpc n_cells; CSR 12 nnz + 24 N"""
+    dpc = dim * (degree + 1) ** dim
+    if operator == "matrix_free":
+        return 16.0 * n_u + 4.0 * dpc * n_cells
+    raise ValueError
+
+
+def cpu_baseline(dim, degree, n, rel_tol):
+    """the oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded sample of the same workload"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    P = pk.Problem.box(dim, [n] * dim, [10.0] * dim, degree, material(), BC_3D[:2 * dim])
+    O = oracle_py.Oracle(P)                      # naive i x q x j assembly (quirk Q6) + SSOR-CG = the reference's algorithm
+    kw = dict(abs_u=1e-12, rel_u=rel_tol, max_it=100000)
+    ta = time.perf_counter(); O.run(0, INPUT["p_init"], INPUT["dt"], **kw); tb = time.perf_counter()      # initialisation only
+    w_init = O.work_counts(reset=True)
+    tc = time.perf_counter(); O.run(1, INPUT["p_init"], INPUT["dt"], **kw); td = time.perf_counter()      # initialisation + 1 time step
+    w_all = O.work_counts(reset=True)
+    w = {k: w_all[k] - w_init[k] for k in w_all}
+    dt_step = max((td - tc) - (tb - ta), 1e-9)
+    upd = dof_updates(w, P.desc.n_dofs_u, P.desc.n_dofs_p, dim)
+    out = {"value": upd / dt_step, "unit": "DoF-updates/s", "cores": 1, "kind": "port",
+           "sample": f"oracle = CPU restatement of the reference (naive assembly + SSOR-CG, g++ -O2, 1 thread); {dim}D Q{degree}/Q1 {n}^{dim} cells "
+                     f"(N_u={P.desc.n_dofs_u}), one time step = {dt_step:.2f} s, {w['apply_u']} A_u applications",
+           "host_cpu": _cpu_name(), "host_cores_available": os.cpu_count()}
+    O.close(); P.close()
+    return out
+
+
+def _cpu_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--degree", type=int, default=2)
+    ap.add_argument("--n", type=int, default=72, help="cells per direction per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--rel-tol", type=float, default=1e-10, help="displacement CG: recursive residual <= max(1e-12, rel_tol*||b||) (SURVEY §7 hard parts)")
+    ap.add_argument("--max-iter", type=int, default=50000)
+    ap.add_argument("--cpu-n", type=int, default=8, help="cells per direction of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch = dist = None
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo")   # control plane only (barrier, max, id broadcast); the data plane is RCCL inside the library
+    except ImportError:
+        torch = None
+
+    dim, deg = args.dim, args.degree
+    n, size = [args.n] * dim, [10.0] * dim
+    if world > 1 and args.scaling == "weak":
+        n[dim - 1] = args.n * world; size[dim - 1] = 10.0 * world
+    P = pk.Problem.box(dim, n, size, deg, material(), BC_3D[:2 * dim], (), rank, world)
+    R = pk.Runner(P, device=local_rank, operator_mode=pk.OP_MATRIX_FREE, p_init=INPUT["p_init"], dt=INPUT["dt"], abs_u=1e-12, rel_u=args.rel_tol, max_it=args.max_iter)
+    G = R.ctx
+    if world > 1:
+        ids = [pk.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        G.comm_rccl(ids[0])
+
+    part = P.desc.part                        # shared interface planes are counted once, by their upper owner
+    own_u = P.desc.n_dofs_u - (part.plane_u if part.has_upper else 0)
+    own_p = P.desc.n_dofs_p - (part.plane_p if part.has_upper else 0)
+    n_cells = P.desc.n_cells
+    if world > 1:
+        t = torch.tensor([own_u, own_p, n_cells], dtype=torch.int64); dist.all_reduce(t)
+        n_u_glob, n_p_glob, n_cells_glob = int(t[0]), int(t[1]), int(t[2])
+    else:
+        n_u_glob, n_p_glob, n_cells_glob = own_u, own_p, n_cells
+
+    def sync():
+        if torch is not None:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    R.initialize()                            # PoroelasticityFSS.h:308-317 (initial equilibrium; not part of a step)
+    for _ in range(args.warmup):
+        R.step()
+    before = R.work()
+    G.timers_reset()                          # HIP events around every kernel family on the launch stream
+    sync()
+    t0 = time.perf_counter()
+    traces = [R.step()[0] for _ in range(args.steps)]
+    sync()
+    elapsed = time.perf_counter() - t0
+    after = R.work()
+    G.timers_enable(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt[0])
+    work = {k: after[k] - before[k] for k in after}
+    updates = dof_updates(work, n_u_glob, n_p_glob, dim)
+
+    # roofline of the dominant kernel: the matrix-free A_u application (per launch, per GPU)
+    t_apply, n_apply = G.timer("apply_u_matrix_free")
+    avg_apply = t_apply / max(n_apply, 1)
+    alg_bytes = bytes_per_apply(dim, deg, P.desc.n_dofs_u, P.desc.n_cells, "matrix_free")
+    achieved = alg_bytes / avg_apply / 1e9 if n_apply else 0.0
+    kernel_time = {k: G.timer(k) for k in ("apply_u_matrix_free", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr",
+                                           "halo_exchange", "allreduce")}
+
+    if rank == 0:
+        out = {
+            "metric": "DoF-updates/sec in assemble+SpMV per fixed-stress iter", "value": updates / elapsed, "unit": "DoF-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{dim}D Q{deg}/Q1 uniform box, {'x'.join(map(str, n))} cells, N_u={n_u_glob}, N_p={n_p_glob}; one time step = one fixed-stress iteration "
+                                   f"(pressure loop + matrix-free Jacobi-PCG displacement solve + strain projection); input.data material/BCs, z-face BCs per SURVEY Q9",
+                       "parallelism": f"z-slab x{world}" if world > 1 else "single GPU", "operator": "matrix_free",
+                       "stopping_rule_u": f"recursive residual <= max(1e-12, {args.rel_tol:g}*||b||), cap {args.max_iter}"},
+            "roofline": {"bound": "hbm", "kernel": "k_mf_apply (matrix-free y = A_u x)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e6 * avg_apply, "launches_timed": n_apply},
+            "work_per_step": {k: work[k] / args.steps for k in work},
+            "kernel_only": {"apply_u_DoF_updates_per_s": (P.desc.n_dofs_u / avg_apply) if n_apply else 0.0,
+                            "seconds_by_family": {k: v[0] for k, v in kernel_time.items()}, "launches_by_family": {k: v[1] for k, v in kernel_time.items()}},
+            "fss_iterations_per_step": [int(len(t)) for t in traces],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dim, deg, args.cpu_n, args.rel_tol)
+        print(json.dumps(out), flush=True)
+    R.close(); P.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

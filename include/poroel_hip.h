@@ -213,7 +213,8 @@ int  poro_apply_operator(poro_ctx *ctx, int which, const double *x_host, double 
 /* repeat y = A_u x `reps` times on device-resident synthetic x; returns mean seconds per application (HIP events) */
 int  poro_bench_operator(poro_ctx *ctx, int which, int operator_mode, int reps, double *seconds_per_apply);
 /* accumulated HIP-event time (s) and launch count of the named kernel family since the last reset */
-int  poro_timers_reset(poro_ctx *ctx);
+int  poro_timers_reset(poro_ctx *ctx);            /* clears the accumulators and switches event timing on */
+int  poro_timers_enable(poro_ctx *ctx, int on);
 int  poro_timers_get(poro_ctx *ctx, const char *name, double *seconds, int64_t *launches);
 
 #ifdef __cplusplus

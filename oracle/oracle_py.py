@@ -55,6 +55,8 @@ def load():
         L.oracle_proj_solve.argtypes = [C.c_void_p, C.c_int32] + slv
         L.oracle_get_volumetric_strain.argtypes = [C.c_void_p]
         L.oracle_noconvergence_count.argtypes = [C.c_void_p]
+        L.oracle_work_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+        L.oracle_work_counts.restype = None
         L.oracle_export_csr_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.oracle_export_csr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), _ip, _dp]
         L.oracle_apply_operator.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
@@ -150,6 +152,11 @@ class Oracle:
 
     def get_volumetric_strain(self):
         self.L.oracle_get_volumetric_strain(self.ptr)
+
+    def work_counts(self, reset=False):
+        out = (C.c_int64 * 6)()
+        self.L.oracle_work_counts(self.ptr, out, int(reset))
+        return dict(zip(("apply_u", "apply_p", "asm_rhs_u", "residual_p", "jacobian_p", "proj_rhs"), list(out)))
 
     def noconvergence_count(self):
         return self.L.oracle_noconvergence_count(self.ptr)

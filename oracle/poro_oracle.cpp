@@ -241,6 +241,7 @@ struct Oracle {
   Csr Pm; std::vector<Vec> proj_rhs, strains;
   Vec eps_v, eps_v0;
   int tensor_to_entry[9];
+  int64_t work[6] = {0, 0, 0, 0, 0, 0};   // apply_u, apply_p, asm_rhs_u, residual_p, jacobian_p, proj_rhs (same units as the host driver's counters)
   int n_noconvergence = 0;  // SolverControl::NoConvergence would have been thrown this many times
 
   explicit Oracle(const poro_desc *dd) : d(*dd) {
@@ -403,6 +404,7 @@ struct Oracle {
       }
     }
     rebuild_system_matrix = false;                                   // :290
+    work[2]++;
     comm.exchange_add(rhs_u, d.part.plane_u);
   }
 
@@ -411,9 +413,10 @@ struct Oracle {
   SolveInfo cg(const Csr &M, Vec &x, const Vec &b, double abs_tol, double rel_tol, int max_iter, int prec, double omega, int64_t plane) {
     const int64_t n = M.n; Vec g(n), dvec(n), h(n), diagv;
     SolveInfo info;
+    int64_t &napply = work[&M == &A ? 0 : 1];
     if (prec == 1 || comm.multi()) { diagv.resize(n); for (int64_t r = 0; r < n; ++r) diagv[r] = M.val[M.diag[r]]; comm.exchange_add(diagv, plane); }
     if (comm.multi() && prec == 2) prec = 1;  // SSOR is rank-local-order dependent; multi-rank oracle uses Jacobi
-    auto apply = [&](Vec &y, const Vec &v) { M.vmult(y, v); comm.exchange_add(y, plane); };
+    auto apply = [&](Vec &y, const Vec &v) { M.vmult(y, v); comm.exchange_add(y, plane); ++napply; };
     auto precond = [&](Vec &y, const Vec &v) {
       if (prec == 2) M.precondition_ssor(y, v, omega);
       else if (prec == 1) for (int64_t r = 0; r < n; ++r) y[r] = v[r] / diagv[r];
@@ -478,10 +481,12 @@ struct Oracle {
     comm.exchange_add(residual, d.part.plane_p);
     well_source(source);                                                                            // :142-147
     for (int64_t i = 0; i < n; ++i) { residual[i] += source[i]; residual[i] *= -1; }                 // :148,152
+    work[3]++;
     return std::sqrt(comm.dot(residual, residual, d.part.plane_p));                                 // PoroelasticityFSS.h:364
   }
   // PoroElasticPressureSolver::assemble_jacobian :158-169
   void assemble_jacobian(double dt) {
+    work[4]++;
     for (size_t j = 0; j < Jp.val.size(); ++j) Jp.val[j] = Mp.val[j] * (1. / mat.biot_M / dt) + (mat.k_over_mu) * Kp.val[j];
   }
   // PoroElasticPressureSolver::solve :172-185
@@ -519,6 +524,7 @@ struct Oracle {
       }
       for (int c = 0; c < ncomp_; ++c) for (int i = 0; i < dpc_p; ++i) proj_rhs[tensor_to_entry[comps[c]]][cdp[cell * dpc_p + i]] += cell_rhs[c][i];   // :191-194
     }
+    work[5]++;
     for (int c = 0; c < ncomp_; ++c) comm.exchange_add(proj_rhs[tensor_to_entry[comps[c]]], d.part.plane_p);
   }
   // StrainProjector::solve_projection_system :201-232
@@ -596,6 +602,7 @@ int oracle_proj_assemble_rhs(oracle_ctx *c, const int32_t *comps, int32_t n) { r
 int oracle_proj_solve(oracle_ctx *c, int32_t entry, double abs_tol, double rel_tol, int max_iter, int prec, double omega, poro_solve_info *info) {
   SolveInfo s = reinterpret_cast<Oracle *>(c)->proj_solve(entry, abs_tol, rel_tol, max_iter, prec, omega); fill_info(s, info); return s.converged ? 0 : 1;
 }
+void oracle_work_counts(oracle_ctx *c, int64_t *out, int reset) { Oracle *o = reinterpret_cast<Oracle *>(c); std::copy(o->work, o->work + 6, out); if (reset) std::fill(o->work, o->work + 6, 0); }
 int oracle_noconvergence_count(oracle_ctx *c) { return reinterpret_cast<Oracle *>(c)->n_noconvergence; }
 int oracle_get_volumetric_strain(oracle_ctx *c) { reinterpret_cast<Oracle *>(c)->get_volumetric_strain(); return 0; }
 int oracle_export_csr_size(oracle_ctx *c, int which, int64_t *n, int64_t *nnz) {
@@ -647,6 +654,10 @@ int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_
     for (int a = 0; a < dim; ++a) o->proj_solve(o->tensor_to_entry[vol[a]], 0.0, 1e-8, max_it, prec, 1.0);
     tph[2] += now() - t0;
   };
+  // setup_dofs() reinit()s every vector to zero (:150-151, PoroElasticPressureSolver.h:103-108, StrainProjector.h:93-96, PoroelasticityFSS.h:145-146)
+  for (Vec *v : {&o->u, &o->rhs_u, &o->dp, &o->p_old, &o->residual, &o->eps_v, &o->eps_v0}) std::fill(v->begin(), v->end(), 0.0);
+  for (Vec &v : o->strains) std::fill(v.begin(), v.end(), 0.0);
+  for (Vec &v : o->proj_rhs) std::fill(v.begin(), v.end(), 0.0);
   std::fill(o->p.begin(), o->p.end(), p_init);                     // :311
   double t0 = now(); std::fill(o->A.val.begin(), o->A.val.end(), 0.0); o->rebuild_system_matrix = true; o->assemble_system(); tph[0] += now() - t0;   // :312
   t0 = now(); SolveInfo su = o->disp_solve(abs_u, rel_u, max_it, prec, om_u); tph[1] += now() - t0;   // :313

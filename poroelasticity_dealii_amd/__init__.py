@@ -83,7 +83,7 @@ HIP_SYMBOLS = [
     "poro_ctx_comm_init_callbacks", "poro_vec_set", "poro_vec_get", "poro_vec_fill", "poro_vec_copy", "poro_vec_axpy", "poro_vec_norm",
     "poro_disp_assemble_system", "poro_disp_solve", "poro_pres_assemble_residual", "poro_pres_assemble_jacobian", "poro_pres_solve",
     "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain",
-    "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_bench_operator", "poro_timers_reset", "poro_timers_get"]
+    "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_bench_operator", "poro_timers_reset", "poro_timers_enable", "poro_timers_get"]
 
 _hip = None
 _host = None
@@ -128,6 +128,7 @@ def load_hip():
         L.poro_apply_operator.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.poro_bench_operator.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
         L.poro_timers_reset.argtypes = [C.c_void_p]
+        L.poro_timers_enable.argtypes = [C.c_void_p, C.c_int]
         L.poro_timers_get.argtypes = [C.c_void_p, C.c_char_p, _dp, C.POINTER(C.c_int64)]
         _hip = L
     return _hip
@@ -152,6 +153,16 @@ def load_host():
         L.poro_host_read_input.argtypes = [C.c_char_p, C.POINTER(InputFlat)]
         L.poro_host_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                                     C.c_double, C.c_double, C.c_int, _dp, C.c_int, C.POINTER(C.c_void_p)]
+        L.poro_host_runner_create.restype = C.c_void_p
+        L.poro_host_runner_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.poro_host_runner_ctx.restype = C.c_void_p
+        L.poro_host_runner_ctx.argtypes = [C.c_void_p]
+        L.poro_host_runner_initialize.argtypes = [C.c_void_p]
+        L.poro_host_runner_step.argtypes = [C.c_void_p, _dp, C.c_int, C.POINTER(C.c_int64)]
+        L.poro_host_runner_work.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.poro_host_runner_work.restype = None
+        L.poro_host_runner_free.argtypes = [C.c_void_p]
+        L.poro_host_runner_free.restype = None
         _host = L
     return _host
 
@@ -328,6 +339,9 @@ class Context:
     def timers_reset(self):
         self._chk(self.L.poro_timers_reset(self.ptr))
 
+    def timers_enable(self, on):
+        self._chk(self.L.poro_timers_enable(self.ptr, int(on)))
+
     def timer(self, name):
         s, n = C.c_double(), C.c_int64()
         self._chk(self.L.poro_timers_get(self.ptr, name.encode(), C.byref(s), C.byref(n)))
@@ -368,3 +382,44 @@ def run_problem(problem, n_steps, p_init, dt, device=0, operator_mode=OP_CSR, fs
     if rows < 0:
         raise RuntimeError(H.poro_host_last_error().decode())
     return trace[:rows], Context(problem, ptr=ctx)
+
+
+WORK_FIELDS = ("apply_u", "apply_p", "asm_rhs_u", "asm_matrix_u", "residual_p", "jacobian_p", "proj_rhs", "cg_u", "cg_p", "cg_proj", "usec_solve_u")
+
+
+class Runner:
+    """Steppable PoroElasticProblem<dim> (C++ host driver): initialize() = PoroelasticityFSS.h:308-317, step() = one pass of :328-407."""
+
+    def __init__(self, problem, device=0, operator_mode=OP_MATRIX_FREE, p_init=10e6, dt=60.0, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
+                 abs_u=1e-12, rel_u=0.0, max_it=1000):
+        self.H = load_host()
+        self.max_fss = max_fss
+        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it)
+        if not h:
+            raise RuntimeError(self.H.poro_host_last_error().decode())
+        self.h = C.c_void_p(h)
+        self.ctx = Context(problem, ptr=C.c_void_p(self.H.poro_host_runner_ctx(self.h)))
+
+    def initialize(self):
+        if self.H.poro_host_runner_initialize(self.h) != 0:
+            raise RuntimeError(self.H.poro_host_last_error().decode())
+
+    def step(self):
+        trace = np.zeros((self.max_fss, 8))
+        work = (C.c_int64 * 11)()
+        rows = self.H.poro_host_runner_step(self.h, trace.ctypes.data_as(_dp), self.max_fss, work)
+        if rows < 0:
+            raise RuntimeError(self.H.poro_host_last_error().decode())
+        return trace[:rows], dict(zip(WORK_FIELDS, list(work)))
+
+    def work(self):
+        """cumulative work counters since creation"""
+        work = (C.c_int64 * 11)()
+        self.H.poro_host_runner_work(self.h, work)
+        return dict(zip(WORK_FIELDS, list(work)))
+
+    def close(self):
+        if self.h:
+            self.ctx.ptr = None          # owned by the runner
+            self.H.poro_host_runner_free(self.h)
+            self.h = None

@@ -109,19 +109,26 @@ struct Rccl {
 #define PORO_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) throw Error(std::string(#x) + " -> " + g_rccl.GetErrorString(r_)); } while (0)
 
 // ---- timing -----------------------------------------------------------------------------------------------------
+// HIP events on the launch stream around every kernel family, drawn from a pool so a timed launch costs two
+// hipEventRecord calls; elapsed times are read back in bulk by timers_collect
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t event_get() {
+  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
 struct Timed {
   poro_ctx *c; Timer *t = nullptr; hipEvent_t a = nullptr, b = nullptr;
   Timed(poro_ctx *c_, const char *name) : c(c_) {
     if (!c->timing) return;
     t = &c->timers[name];
-    (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream);
+    a = event_get(); b = event_get(); (void)hipEventRecord(a, c->stream);
   }
   ~Timed() { if (!t) return; (void)hipEventRecord(b, c->stream); t->pending.emplace_back(a, b); t->launches++; }
 };
 void timers_collect(poro_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->timers) {
-    for (auto &p : kv.second.pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.first, p.second); kv.second.seconds += ms * 1e-3; (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : kv.second.pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.first, p.second); kv.second.seconds += ms * 1e-3; g_event_pool.push_back(p.first); g_event_pool.push_back(p.second); }
     kv.second.pending.clear();
   }
 }
@@ -598,6 +605,7 @@ int poro_bench_operator(poro_ctx *c, int which, int operator_mode, int reps, dou
 }
 
 int poro_timers_reset(poro_ctx *c) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); timers_collect(c); c->timers.clear(); c->timing = true; return 0; }); }
+int poro_timers_enable(poro_ctx *c, int on) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); timers_collect(c); c->timing = on != 0; return 0; }); }
 int poro_timers_get(poro_ctx *c, const char *name, double *seconds, int64_t *launches) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device)); timers_collect(c);

@@ -90,7 +90,7 @@ int poro_host_read_input(const char *path /* NULL = declared defaults */, poro_i
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
-// PoroElasticProblem<dim>::run() on the HIP back end (problem.hpp).  trace layout = oracle_run's.
+// PoroElasticProblem<dim>::run() on the HIP back end (problem.hpp).  trace rows: see PoroElasticProblem::time_step.
 int poro_host_run(void *problem_data, int device, int operator_mode, double p_init, double dt, int n_steps,
                   double fss_tol, double pressure_tol, int max_fss, int max_pres,
                   double abs_u, double rel_u, int max_it, double *trace, int max_rows, poro_ctx **ctx_out) {
@@ -104,5 +104,47 @@ int poro_host_run(void *problem_data, int device, int operator_mode, double p_in
     return rows;
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+
+// Steppable driver for bench.py: the same PoroElasticProblem object, one time step per call.
+struct HostRunner {
+  int dim; RunControls rc; PoroElasticProblem<2> *p2 = nullptr; PoroElasticProblem<3> *p3 = nullptr;
+  ~HostRunner() { delete p2; delete p3; }
+};
+void *poro_host_runner_create(void *problem_data, int device, int operator_mode, double p_init, double dt, double fss_tol, double pressure_tol,
+                              int max_fss, int max_pres, double abs_u, double rel_u, int max_it) {
+  try {
+    auto *P = static_cast<ProblemData *>(problem_data);
+    auto *R = new HostRunner(); R->dim = P->mesh.dim;
+    R->rc.p_init = p_init; R->rc.time_step = dt; R->rc.fss_tol = fss_tol; R->rc.pressure_tol = pressure_tol; R->rc.max_fss_iterations = max_fss;
+    R->rc.max_pressure_iterations = max_pres; R->rc.abs_tol_u = abs_u; R->rc.rel_tol_u = rel_u; R->rc.max_iter = max_it;
+    if (R->dim == 2) R->p2 = new PoroElasticProblem<2>(*P, device, operator_mode); else R->p3 = new PoroElasticProblem<3>(*P, device, operator_mode);
+    return R;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+poro_ctx *poro_host_runner_ctx(void *r) { auto *R = static_cast<HostRunner *>(r); return R->dim == 2 ? R->p2->context() : R->p3->context(); }
+int poro_host_runner_initialize(void *r) {
+  try { auto *R = static_cast<HostRunner *>(r); if (R->dim == 2) R->p2->initialize(R->rc); else R->p3->initialize(R->rc); return 0; }
+  catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+// one time step; trace rows as poro_host_run; work[11] = apply_u, apply_p, asm_rhs_u, asm_matrix_u, residual_p, jacobian_p, proj_rhs, cg_u, cg_p, cg_proj, seconds_solve_u*1e6
+int poro_host_runner_step(void *r, double *trace, int max_rows, int64_t *work) {
+  try {
+    auto *R = static_cast<HostRunner *>(r);
+    auto fill = [&](auto &w) { work[0] = w.apply_u; work[1] = w.apply_p; work[2] = w.asm_rhs_u; work[3] = w.asm_matrix_u; work[4] = w.residual_p; work[5] = w.jacobian_p;
+                               work[6] = w.proj_rhs; work[7] = w.cg_u; work[8] = w.cg_p; work[9] = w.cg_proj; work[10] = (int64_t)(w.seconds_solve_u * 1e6); };
+    int rows;
+    if (R->dim == 2) { rows = R->p2->time_step(R->rc, trace, max_rows); if (work) fill(R->p2->work); }
+    else { rows = R->p3->time_step(R->rc, trace, max_rows); if (work) fill(R->p3->work); }
+    return rows;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+// cumulative work counters since creation (same layout as poro_host_runner_step's `work`)
+void poro_host_runner_work(void *r, int64_t *work) {
+  auto *R = static_cast<HostRunner *>(r);
+  auto fill = [&](auto &w) { work[0] = w.apply_u; work[1] = w.apply_p; work[2] = w.asm_rhs_u; work[3] = w.asm_matrix_u; work[4] = w.residual_p; work[5] = w.jacobian_p;
+                             work[6] = w.proj_rhs; work[7] = w.cg_u; work[8] = w.cg_p; work[9] = w.cg_proj; work[10] = (int64_t)(w.seconds_solve_u * 1e6); };
+  if (R->dim == 2) fill(R->p2->work); else fill(R->p3->work);
+}
+void poro_host_runner_free(void *r) { delete static_cast<HostRunner *>(r); }
 
 }  // extern "C"

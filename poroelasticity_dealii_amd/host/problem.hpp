@@ -153,55 +153,77 @@ template <int dim> class PoroElasticProblem {
   void setup_dofs() {                                      // :131-151
     pressure_solver.setup_dofs(); displacement_solver.setup_dofs();
     strain_projector.set_solvers(ctx); strain_projector.setup_dofs();
+    // every reinit() of the reference's setup_dofs leaves a zero vector (PoroElasticDisplacementSolver.h:150-151,
+    // PoroElasticPressureSolver.h:103-108, StrainProjector.h:93-96, PoroelasticityFSS.h:145-146)
+    const int n_sym = dim * (dim + 1) / 2;
+    for (int id : {PORO_VEC_U, PORO_VEC_RHS_U, PORO_VEC_P, PORO_VEC_P_OLD, PORO_VEC_DP, PORO_VEC_RESIDUAL_P, PORO_VEC_EPSV, PORO_VEC_EPSV0})
+      check(poro_vec_fill(ctx, id, 0.0), "vec_fill");
+    for (int e = 0; e < n_sym; ++e) { check(poro_vec_fill(ctx, PORO_VEC_STRAIN0 + e, 0.0), "vec_fill"); check(poro_vec_fill(ctx, PORO_VEC_PROJ_RHS0 + e, 0.0), "vec_fill"); }
   }
   void get_normal_strain_components() {                    // :153-164
     strain_projector.assemble_projection_rhs(strain_tensor_volumetric_components);
-    for (const auto &comp : strain_tensor_volumetric_components) strain_projector.solve_projection_system(tensor_indexer.entryIndex(comp));
+    for (const auto &comp : strain_tensor_volumetric_components) {
+      strain_projector.solve_projection_system(tensor_indexer.entryIndex(comp));
+      work.cg_proj += strain_projector.last.iterations; work.apply_p += strain_projector.last.operator_applications;
+    }
   }
   void get_volumetric_strain() { check(poro_get_volumetric_strain(ctx), "get_volumetric_strain"); }   // :179-186
 
+  // work counters of the metric "DoF-updates in assemble + SpMV" (SURVEY 8d): operator applications and assembly passes
+  struct Work { int64_t apply_u = 0, apply_p = 0, asm_rhs_u = 0, asm_matrix_u = 0, residual_p = 0, jacobian_p = 0, proj_rhs = 0;
+                int64_t cg_u = 0, cg_p = 0, cg_proj = 0; double seconds_solve_u = 0; } work;
+
   // trace rows: [step, fss_iteration, pressure_iterations, inner pressure error, |p|_inf, error after displacement, u CG its, p CG its]
-  int run(const RunControls &rc, double *trace, int max_rows) {
-    int rows = 0;
+  void initialize(const RunControls &rc) {
     displacement_solver.control.abs_tol = rc.abs_tol_u; displacement_solver.control.rel_tol = rc.rel_tol_u;
     displacement_solver.control.max_iter = pressure_solver.control.max_iter = strain_projector.control.max_iter = rc.max_iter;
     setup_dofs();                                          // :308
     pressure_solver.solution = rc.p_init;                  // :311
-    displacement_solver.assemble_system(pressure_solver.solution);   // :312
-    displacement_solver.solve();                           // :313
+    assemble_displacement();                               // :312
+    solve_displacement();                                  // :313
     strain_projector.assemble_projection_matrix();         // :314
-    get_normal_strain_components();                        // :315
+    normal_strains();                                      // :315
     get_volumetric_strain();                               // :316
     initial_volumetric_strain = volumetric_strain;         // :317
-    if (rows < max_rows) { double *r = trace + 8 * rows++; for (int i = 0; i < 8; ++i) r[i] = 0; r[6] = displacement_solver.last.iterations; }
-    double pressure_error;
-    for (int time_step_number = 1; time_step_number <= rc.n_steps; ++time_step_number) {   // :327-329
-      pressure_solver.old_solution = pressure_solver.solution;   // :342
-      pressure_error = rc.pressure_tol * 2; int fss_iteration = 0;   // :345-346
-      while (fss_iteration < rc.max_fss_iterations && pressure_error > rc.fss_tol) {   // :347-348
-        fss_iteration++;
-        int pressure_iteration = 0, pcg = 0; double inner = 0;
-        pressure_solver.solution_update = 0.0;             // :356
-        while (pressure_iteration < rc.max_pressure_iterations) {   // :358
-          pressure_iteration++;
-          pressure_solver.update_volumetric_strain(volumetric_strain);   // :360
-          pressure_solver.assemble_residual(rc.time_step, volumetric_strain, initial_volumetric_strain);   // :361-363
-          pressure_error = pressure_solver.residual_l2;    // :364
-          inner = pressure_error;
-          if (pressure_error < rc.pressure_tol) break;     // :366-371
-          pressure_solver.assemble_jacobian(rc.time_step); // :377
-          pressure_solver.solve(); pcg += pressure_solver.last.iterations;   // :378
-          pressure_solver.solution += pressure_solver.solution_update;   // :379
-        }
-        const double pinf = pressure_solver.solution.linfty_norm();   // :387-389
-        displacement_solver.assemble_system(pressure_solver.solution);   // :395
-        displacement_solver.solve();                       // :396
-        get_normal_strain_components();                    // :398  (get_volumetric_strain() stays commented out, :399)
-        pressure_solver.assemble_residual(rc.time_step, volumetric_strain, initial_volumetric_strain);   // :402-404
-        pressure_error = pressure_solver.residual_l2;      // :405
-        if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = time_step_number; r[1] = fss_iteration; r[2] = pressure_iteration - 1; r[3] = inner; r[4] = pinf; r[5] = pressure_error; r[6] = displacement_solver.last.iterations; r[7] = pcg; }
+    time_step_number = 0;
+  }
+  // one pass of the time loop body (:328-407); returns the number of trace rows written (= FSS iterations)
+  int time_step(const RunControls &rc, double *trace, int max_rows) {
+    int rows = 0;
+    time_step_number++;                                    // :329
+    pressure_solver.old_solution = pressure_solver.solution;   // :342
+    double pressure_error = rc.pressure_tol * 2; int fss_iteration = 0;   // :345-346
+    while (fss_iteration < rc.max_fss_iterations && pressure_error > rc.fss_tol) {   // :347-348
+      fss_iteration++;
+      int pressure_iteration = 0, pcg = 0; double inner = 0;
+      pressure_solver.solution_update = 0.0;               // :356
+      while (pressure_iteration < rc.max_pressure_iterations) {   // :358
+        pressure_iteration++;
+        pressure_solver.update_volumetric_strain(volumetric_strain);   // :360
+        pressure_solver.assemble_residual(rc.time_step, volumetric_strain, initial_volumetric_strain); work.residual_p++;   // :361-363
+        pressure_error = pressure_solver.residual_l2;      // :364
+        inner = pressure_error;
+        if (pressure_error < rc.pressure_tol) break;       // :366-371
+        pressure_solver.assemble_jacobian(rc.time_step); work.jacobian_p++;   // :377
+        pressure_solver.solve();                           // :378
+        pcg += pressure_solver.last.iterations; work.cg_p += pressure_solver.last.iterations; work.apply_p += pressure_solver.last.operator_applications;
+        pressure_solver.solution += pressure_solver.solution_update;   // :379
       }
+      const double pinf = pressure_solver.solution.linfty_norm();   // :387-389
+      assemble_displacement();                             // :395
+      solve_displacement();                                // :396
+      normal_strains();                                    // :398  (get_volumetric_strain() stays commented out, :399)
+      pressure_solver.assemble_residual(rc.time_step, volumetric_strain, initial_volumetric_strain); work.residual_p++;   // :402-404
+      pressure_error = pressure_solver.residual_l2;        // :405
+      if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = time_step_number; r[1] = fss_iteration; r[2] = pressure_iteration - 1; r[3] = inner; r[4] = pinf; r[5] = pressure_error; r[6] = displacement_solver.last.iterations; r[7] = pcg; }
     }
+    return rows;
+  }
+  int run(const RunControls &rc, double *trace, int max_rows) {
+    int rows = 0;
+    initialize(rc);
+    if (rows < max_rows) { double *r = trace + 8 * rows++; for (int i = 0; i < 8; ++i) r[i] = 0; r[6] = displacement_solver.last.iterations; }
+    for (int s = 1; s <= rc.n_steps; ++s) rows += time_step(rc, trace + 8 * rows, max_rows - rows);   // :327
     return rows;
   }
 
@@ -213,6 +235,15 @@ template <int dim> class PoroElasticProblem {
   std::vector<int> strain_tensor_volumetric_components;            // :86
 
  private:
+  void assemble_displacement() { const bool rebuild = first_assembly; displacement_solver.assemble_system(pressure_solver.solution); first_assembly = false; work.asm_rhs_u++; if (rebuild) work.asm_matrix_u++; }
+  void solve_displacement() {
+    displacement_solver.solve();
+    work.cg_u += displacement_solver.last.iterations; work.apply_u += displacement_solver.last.operator_applications; work.seconds_solve_u += displacement_solver.last.seconds;
+  }
+  void normal_strains() {
+    get_normal_strain_components(); work.proj_rhs++;
+  }
+  bool first_assembly = true; int time_step_number = 0;
   static poro_ctx *make_ctx(ProblemData &P, int device, int operator_mode) {
     poro_ctx *c = nullptr;
     check(poro_ctx_create(&P.d, device, operator_mode, &c), "poro_ctx_create");

@@ -1,0 +1,60 @@
+"""Worker of the multi-rank CPU tests: one process per rank, gloo, each rank runs the ORACLE on its slab with the
+exchange / all-reduce callbacks wired to torch.distributed (the same callback interface the HIP library takes).
+Usage: python mr_worker.py rank world port dim nx,ny[,nz] degree out.npz"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), HERE]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import poroelasticity_dealii_amd as pk  # noqa: E402
+import oracle_py  # noqa: E402
+from common import REF, box_problem  # noqa: E402
+
+
+def main():
+    rank, world, port, dim = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    n = [int(v) for v in sys.argv[5].split(",")]; deg = int(sys.argv[6]); out = sys.argv[7]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+    def allreduce(buf):
+        t = torch.from_numpy(buf.copy()); dist.all_reduce(t); buf[:] = t.numpy()
+
+    def sendrecv(send, recv, peer):
+        ts, tr = torch.from_numpy(send.copy()), torch.empty(len(recv), dtype=torch.float64)
+        reqs = [dist.isend(ts, peer), dist.irecv(tr, peer)]
+        for r in reqs:
+            r.wait()
+        recv[:] = tr.numpy()
+
+    P = box_problem(dim, n, deg, rank=rank, n_ranks=world)
+    O = oracle_py.Oracle(P, hoisted=True)
+    O.comm_callbacks(allreduce, sendrecv)
+    # one full time step of the reference loop, Jacobi-CG on every rank (SSOR sweeps are rank-order dependent)
+    tr, _ = O.run(1, REF["p_init"], REF["dt"], max_it=20000, prec=oracle_py.PREC_JACOBI)
+    res = {"trace": tr, "u": O.get(pk.VEC_U), "p": O.get(pk.VEC_P), "epsv": O.get(pk.VEC_EPSV), "rhs_u": O.get(pk.VEC_RHS_U),
+           "residual": O.get(pk.VEC_RESIDUAL_P), "noconv": np.array([O.noconvergence_count()])}
+    # operator application with a globally defined x (the slab takes its window of it)
+    nn = [deg * m + 1 for m in n]
+    plane = dim * int(np.prod(nn[:-1]))
+    base = [0]
+    for r in range(world):
+        Pr = box_problem(dim, n, deg, rank=r, n_ranks=world)
+        base.append(base[-1] + Pr.desc.n_dofs_u - plane); Pr.close()
+    xg = np.sin(0.11 * np.arange(base[-1] + plane))
+    x = xg[base[rank]: base[rank] + P.desc.n_dofs_u]
+    res["Ax"] = O.apply(pk.MAT_A_U, x)
+    res["offset_u"] = np.array([base[rank]])
+    np.savez(out, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -169,7 +169,9 @@ def test_run_trace_matches_oracle(cfg):
             assert np.allclose(t1[:, 4], t0[:, 4], rtol=1e-10)               # |p|_inf
             assert rel2(G.get(pk.VEC_P), O.get(pk.VEC_P)) <= 1e-10
             assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-8
-            assert rel2(G.get(pk.VEC_EPSV), O.get(pk.VEC_EPSV)) <= 1e-8
+            # eps_v comes from projections both sides stop at the reference's 1e-8*||rhs|| (StrainProjector.h:209) with
+            # different preconditioners, so they agree to ~cond(M)*1e-8, not to solver-independent precision
+            assert rel2(G.get(pk.VEC_EPSV), O.get(pk.VEC_EPSV)) <= 1e-6
         finally:
             G.close()
     finally:

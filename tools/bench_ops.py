@@ -1,0 +1,30 @@
+"""Operator micro-benchmark: mean seconds per y = A_u x (HIP events around `reps` back-to-back launches)."""
+import json, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import poroelasticity_dealii_amd as pk
+from bench import material, BC_3D, bytes_per_apply
+
+def run(dim, n, deg, mode, reps=50):
+    t0 = time.time()
+    P = pk.Problem.box(dim, [n] * dim, [10.0] * dim, deg, material(), BC_3D[:2 * dim])
+    t1 = time.time()
+    G = pk.Context(P, 0, mode)
+    t2 = time.time()
+    G.fill(pk.VEC_P, 10e6); G.disp_assemble_system(True)
+    t3 = time.time()
+    sec = G.bench_operator(mode, reps)
+    nu, nc = P.desc.n_dofs_u, P.desc.n_cells
+    if mode == pk.OP_MATRIX_FREE:
+        b = bytes_per_apply(dim, deg, nu, nc, "matrix_free")
+    else:
+        rp, col, val = None, None, None
+        import ctypes as C
+        nr, nnz = C.c_int64(), C.c_int64(); G.L.poro_export_csr_size(G.ptr, pk.MAT_A_U, C.byref(nr), C.byref(nnz)); b = 12.0 * nnz.value + 24.0 * nu
+    print(json.dumps({"dim": dim, "n": n, "deg": deg, "mode": "mf" if mode else "csr", "N_u": nu, "us_per_apply": sec * 1e6, "GBs_algorithmic": b / sec / 1e9,
+                      "GDoF_per_s": nu / sec / 1e9, "host_mesh_s": t1 - t0, "ctx_s": t2 - t1, "assemble_s": t3 - t2}), flush=True)
+    G.close(); P.close()
+
+if __name__ == "__main__":
+    for spec in sys.argv[1:]:
+        dim, n, deg, mode = spec.split(",")
+        run(int(dim), int(n), int(deg), pk.OP_MATRIX_FREE if mode == "mf" else pk.OP_CSR)
