@@ -1,6 +1,7 @@
 """Worker of the multi-rank CPU tests: one process per rank, gloo, each rank runs the ORACLE on its slab with the
 exchange / all-reduce callbacks wired to torch.distributed (the same callback interface the HIP library takes).
-Usage: python mr_worker.py rank world port dim nx,ny[,nz] degree out.npz"""
+Usage: python mr_worker.py rank world port dim nx,ny[,nz] degree out.npz [oracle|hip_csr|hip_mf]
+With a hip_* backend every rank drives the HIP library (all ranks share GPU 0; halos / dots are host-staged through the callbacks)."""
 import os
 import sys
 
@@ -33,13 +34,23 @@ def main():
             r.wait()
         recv[:] = tr.numpy()
 
+    backend = sys.argv[8] if len(sys.argv) > 8 else "oracle"
     P = box_problem(dim, n, deg, rank=rank, n_ranks=world)
-    O = oracle_py.Oracle(P, hoisted=True)
-    O.comm_callbacks(allreduce, sendrecv)
-    # one full time step of the reference loop, Jacobi-CG on every rank (SSOR sweeps are rank-order dependent)
-    tr, _ = O.run(1, REF["p_init"], REF["dt"], max_it=20000, prec=oracle_py.PREC_JACOBI)
+    if backend == "oracle":
+        O = oracle_py.Oracle(P, hoisted=True)
+        O.comm_callbacks(allreduce, sendrecv)
+        # one full time step of the reference loop, Jacobi-CG on every rank (SSOR sweeps are rank-order dependent)
+        tr, _ = O.run(1, REF["p_init"], REF["dt"], max_it=20000, prec=oracle_py.PREC_JACOBI)
+        noconv = O.noconvergence_count()
+    else:
+        R = pk.Runner(P, device=0, operator_mode=pk.OP_MATRIX_FREE if backend == "hip_mf" else pk.OP_CSR, p_init=REF["p_init"], dt=REF["dt"], max_it=20000)
+        O = R.ctx
+        O.comm_callbacks(allreduce, sendrecv)
+        R.initialize()
+        t1, _ = R.step()
+        tr = np.vstack([np.zeros((1, 8)), t1]); noconv = 0
     res = {"trace": tr, "u": O.get(pk.VEC_U), "p": O.get(pk.VEC_P), "epsv": O.get(pk.VEC_EPSV), "rhs_u": O.get(pk.VEC_RHS_U),
-           "residual": O.get(pk.VEC_RESIDUAL_P), "noconv": np.array([O.noconvergence_count()])}
+           "residual": O.get(pk.VEC_RESIDUAL_P), "noconv": np.array([noconv])}
     # operator application with a globally defined x (the slab takes its window of it)
     nn = [deg * m + 1 for m in n]
     plane = dim * int(np.prod(nn[:-1]))

@@ -1,0 +1,48 @@
+"""The partitioned HIP path (slab partition + interface exchange + all-reduced dots inside the device PCG) on ONE GPU:
+2 ranks share device 0 and exchange through the host-staged callback communicator (gloo); on a multi-GPU node the same
+code runs with RCCL (poro_ctx_comm_init_rccl).  Compared with the single-rank oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import poroelasticity_dealii_amd as pk
+import oracle_py
+from common import REF, box_problem
+from test_multirank_cpu import HERE, free_port, stitch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dim,n,deg,backend", [(3, (3, 3, 6), 2, "hip_mf"), (3, (4, 4, 6), 1, "hip_csr"), (2, (8, 12), 2, "hip_mf")])
+def test_two_ranks_on_one_gpu(tmp_path, dim, n, deg, backend):
+    world, port = 2, free_port()
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mr_worker.py"), str(r), str(world), str(port), str(dim), ",".join(map(str, n)), str(deg), outs[r], backend])
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    R = [np.load(o) for o in outs]
+    P = box_problem(dim, n, deg)
+    O = oracle_py.Oracle(P, hoisted=True)
+    tr, _ = O.run(1, REF["p_init"], REF["dt"], max_it=20000, prec=oracle_py.PREC_JACOBI)
+    nn = [deg * m + 1 for m in n]
+    plane_u = dim * int(np.prod(nn[:-1])); plane_p = int(np.prod([m + 1 for m in n[:-1]]))
+    off_u = [int(r["offset_u"][0]) for r in R]
+    off_p = [0, R[0]["p"].size - plane_p]
+    for r in R:
+        assert np.array_equal(r["trace"][1:, :3], tr[1:, :3])
+    u = stitch([r["u"] for r in R], off_u, plane_u, P.desc.n_dofs_u)
+    p = stitch([r["p"] for r in R], off_p, plane_p, P.desc.n_dofs_p)
+    rhs = stitch([r["rhs_u"] for r in R], off_u, plane_u, P.desc.n_dofs_u)
+    assert np.abs(R[0]["u"][-plane_u:] - R[1]["u"][:plane_u]).max() <= 1e-14 * np.abs(u).max()
+    # the rhs after the step depends on p, which both sides converge to the reference's 1e-8 tolerances only
+    assert np.linalg.norm(rhs - O.get(pk.VEC_RHS_U)) <= 1e-9 * np.linalg.norm(rhs)
+    assert np.linalg.norm(u - O.get(pk.VEC_U)) <= 1e-8 * np.linalg.norm(u)
+    assert np.linalg.norm(p - O.get(pk.VEC_P)) <= 1e-10 * np.linalg.norm(p)
+    Ax = stitch([r["Ax"] for r in R], off_u, plane_u, P.desc.n_dofs_u)
+    y = O.apply(pk.MAT_A_U, np.sin(0.11 * np.arange(P.desc.n_dofs_u)))
+    assert np.abs(Ax - y).max() <= 1e-12 * np.abs(y).max()
+    O.close(); P.close()
