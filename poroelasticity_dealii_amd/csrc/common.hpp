@@ -97,6 +97,7 @@ struct poro_ctx {
   poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
+  int n_cus = 256; int mf_variant = 1 /* 0 element-matrix gather, 1 sum-factorised (where supported) */; int mask_anywhere = 0;
   // timing
   bool timing = false; std::map<std::string, poro::Timer> timers;
   double jac_dt = -1;
@@ -153,8 +154,12 @@ void asm_proj_rhs(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t
                   double *const *rhs /*host array of device ptrs*/);
 
 // ---- kernels_mf.hip -----------------------------------------------------------------------------
-struct MfArgs { int dim, k_u; BoxDev box; const double *Ke; const uint8_t *mask; const double *diag_local; };
+struct MfArgs { int dim, k_u; BoxDev box; const double *Ke; const uint8_t *mask; const double *diag_local; double lam, G; int mask_anywhere; };
 void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained);
 void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
+
+// ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
+bool kron_supported(int dim, int k_u);
+void kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus);
 
 }  // namespace poro

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -180,7 +181,15 @@ AsmArgs asm_args(poro_ctx *c) {
   a.cell_dofs_u = c->cell_dofs_u.p; a.cell_dofs_p = c->cell_dofs_p.p; a.cell_X = c->cell_X.p; a.dir_mask = c->dir_mask.p; a.dir_val = c->dir_val.p; a.mat = c->mat;
   return a;
 }
-MfArgs mf_args(poro_ctx *c) { MfArgs a{}; a.dim = c->dim; a.k_u = c->k_u; a.box = c->box; a.Ke = c->Ke.p; a.mask = c->dir_mask.p; a.diag_local = c->diag_u_local.p; return a; }
+MfArgs mf_args(poro_ctx *c) {
+  MfArgs a{}; a.dim = c->dim; a.k_u = c->k_u; a.box = c->box; a.Ke = c->Ke.p; a.mask = c->dir_mask.p; a.diag_local = c->diag_u_local.p;
+  a.lam = c->mat.lame_lambda; a.G = c->mat.shear_G; a.mask_anywhere = c->mask_anywhere; return a;
+}
+// y = A_u x without forming A_u: sum-factorised sweeps where available, element-matrix gather otherwise
+void mf_operator(poro_ctx *c, const double *x, double *y, bool constrained) {
+  if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) kron_apply(c->stream, mf_args(c), x, y, constrained, c->n_cus);
+  else mf_apply(c->stream, mf_args(c), x, y, constrained);
+}
 
 double *vec(poro_ctx *c, int which) {
   auto it = c->vec.find(which);
@@ -193,7 +202,7 @@ bool is_u_vec(int which) { return which == PORO_VEC_U || which == PORO_VEC_RHS_U
 void apply_A_u(poro_ctx *c, const double *x, double *y, int mode) {
   {
     Timed tm(c, mode == PORO_OP_MATRIX_FREE ? "apply_u_matrix_free" : "apply_u_csr");
-    if (mode == PORO_OP_MATRIX_FREE) mf_apply(c->stream, mf_args(c), x, y, true);
+    if (mode == PORO_OP_MATRIX_FREE) mf_operator(c, x, y, true);
     else la_csr_spmv(c->stream, c->Au, c->Au_val.p, x, y);
   }
   exchange_add(c, y, c->n_u, c->comm.part.plane_u);
@@ -269,6 +278,8 @@ void setup(poro_ctx *c, const poro_desc *d) {
       }
     }
   }
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount; }
+  if (const char *v = std::getenv("PORO_MF_VARIANT")) c->mf_variant = (std::string(v) == "gather" || std::string(v) == "0") ? 0 : 1;
   c->box.enabled = d->box.enabled;
   for (int k = 0; k < 3; ++k) { c->box.n[k] = d->box.enabled && k < c->dim ? d->box.n[k] : 1; c->box.h[k] = d->box.h[k]; c->box.nn[k] = c->k_u * c->box.n[k] + 1; }
 
@@ -291,6 +302,13 @@ void setup(poro_ctx *c, const poro_desc *d) {
   { std::vector<uint8_t> m(c->n_u, 0); std::vector<double> v(c->n_u, 0.0);
     for (int64_t i = 0; i < d->n_dirichlet; ++i) { const int32_t dof = d->dirichlet_dof[i]; if (dof < 0 || dof >= c->n_u) throw Error("dirichlet_dof out of range"); m[dof] = 1; v[dof] = d->dirichlet_value[i]; }
     c->dir_mask.upload(m); c->dir_val.upload(v);
+    if (d->box.enabled) {   // are all constrained dofs on the box boundary?  (lets the matrix-free kernels skip mask loads in the interior)
+      int64_t nn[3] = {1, 1, 1}; for (int k = 0; k < c->dim; ++k) nn[k] = (int64_t)c->k_u * d->box.n[k] + 1;
+      for (int64_t i = 0; i < d->n_dirichlet; ++i) {
+        const int64_t node = d->dirichlet_dof[i] / c->dim; const int64_t ci = node % nn[0], cj = (node / nn[0]) % nn[1], ck = node / (nn[0] * nn[1]);
+        if (!(ci == 0 || ci == nn[0] - 1 || cj == 0 || cj == nn[1] - 1 || (c->dim == 3 && (ck == 0 || ck == nn[2] - 1)))) { c->mask_anywhere = 1; break; }
+      }
+    }
     c->h_dir_dof.assign(d->dirichlet_dof, d->dirichlet_dof + d->n_dirichlet); c->h_dir_val.assign(d->dirichlet_value, d->dirichlet_value + d->n_dirichlet); }
   c->n_bfaces = d->n_bfaces; c->n_neumann = d->n_neumann;
   if (d->n_bfaces) { c->bface_cell.upload(d->bface_cell, d->n_bfaces); c->bface_local.upload(d->bface_local, d->n_bfaces); c->bface_id.upload(d->bface_id, d->n_bfaces); }
@@ -423,7 +441,19 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
         asm_u_element_matrix(s, a, 0, c->Ke.p);
         mf_diag(s, mf_args(c), c->diag_u_local.p);
         // lifting: -(A_full g) on the free rows, through the unconstrained operator
-        mf_apply(s, mf_args(c), c->dir_val.p, c->wh_u.p, false);
+        mf_operator(c, c->dir_val.p, c->wh_u.p, false);
+        if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
+          // self-check of the sum-factorised operator against the element-matrix gather on a synthetic vector (guards the
+          // FE-table / numbering assumptions of the structured path); both unconstrained
+          std::vector<double> hx(c->n_u); for (int64_t i = 0; i < c->n_u; ++i) hx[i] = std::sin(0.37 * (double)i);
+          DevBuf<double> tx, t1, t2; tx.upload(hx); t1.alloc(c->n_u); t2.alloc(c->n_u);
+          kron_apply(s, mf_args(c), tx.p, t1.p, false, c->n_cus); mf_apply(s, mf_args(c), tx.p, t2.p, false);
+          la_axpy(s, t1.p, -1.0, t2.p, c->n_u);
+          la_norm_partials(s, t1.p, c->n_u, c->partials.p, c->partials.p + kMaxPartials); la_norm_partials(s, t2.p, c->n_u, c->partials.p + 2 * kMaxPartials, c->partials.p + 3 * kMaxPartials);
+          la_reduce_finish(s, c->partials.p, 4, c->red.p, 2 | 8);
+          double h[4]; PORO_HIP(hipMemcpyAsync(h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+          if (!(h[1] <= 1e-11 * h[3])) throw Error("sum-factorised operator disagrees with the element-matrix operator: max diff " + std::to_string(h[1]) + " vs max " + std::to_string(h[3]));
+        }
         la_fill(s, c->lift_u.p, 0.0, c->n_u); la_axpy(s, c->lift_u.p, -1.0, c->wh_u.p, c->n_u);
       }
       asm_u_neumann(s, a, c->n_bfaces, c->bface_cell.p, c->bface_local.p, c->bface_id.p, c->n_neumann, c->neu_label.p, c->neu_comp.p, c->neu_val.p, c->neumann_u.p);
