@@ -82,7 +82,7 @@ struct poro_ctx {
   poro::DevBuf<double> cell_X, tables;
   poro::FeTablesDev fe{};
   std::vector<int64_t> color_off;            // host offsets into color_cells
-  poro::DevBuf<uint8_t> dir_mask; poro::DevBuf<double> dir_val;
+  poro::DevBuf<uint8_t> dir_mask, node_mask; poro::DevBuf<double> dir_val; poro::DevBuf<int32_t> dir_dofs;
   std::vector<int32_t> h_dir_dof; std::vector<double> h_dir_val;
   poro::DevBuf<int32_t> bface_cell, bface_local, bface_id, neu_label, neu_comp; poro::DevBuf<double> neu_val;
   int64_t n_bfaces = 0; int n_neumann = 0;
@@ -154,7 +154,7 @@ void asm_proj_rhs(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t
                   double *const *rhs /*host array of device ptrs*/);
 
 // ---- kernels_mf.hip -----------------------------------------------------------------------------
-struct MfArgs { int dim, k_u; BoxDev box; const double *Ke; const uint8_t *mask; const double *diag_local; double lam, G; int mask_anywhere; };
+struct MfArgs { int dim, k_u; BoxDev box; const double *Ke; const uint8_t *mask; const double *diag_local; double lam, G; int mask_anywhere; const uint8_t *nodemask; const int32_t *dirichlet_dofs; int64_t n_dirichlet; };
 void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained);
 void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
 

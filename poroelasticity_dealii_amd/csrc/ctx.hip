@@ -183,7 +183,8 @@ AsmArgs asm_args(poro_ctx *c) {
 }
 MfArgs mf_args(poro_ctx *c) {
   MfArgs a{}; a.dim = c->dim; a.k_u = c->k_u; a.box = c->box; a.Ke = c->Ke.p; a.mask = c->dir_mask.p; a.diag_local = c->diag_u_local.p;
-  a.lam = c->mat.lame_lambda; a.G = c->mat.shear_G; a.mask_anywhere = c->mask_anywhere; return a;
+  a.lam = c->mat.lame_lambda; a.G = c->mat.shear_G; a.mask_anywhere = c->mask_anywhere;
+  a.nodemask = c->node_mask.p; a.dirichlet_dofs = c->dir_dofs.p; a.n_dirichlet = (int64_t)c->dir_dofs.n; return a;
 }
 // y = A_u x without forming A_u: sum-factorised sweeps where available, element-matrix gather otherwise
 void mf_operator(poro_ctx *c, const double *x, double *y, bool constrained) {
@@ -302,6 +303,8 @@ void setup(poro_ctx *c, const poro_desc *d) {
   { std::vector<uint8_t> m(c->n_u, 0); std::vector<double> v(c->n_u, 0.0);
     for (int64_t i = 0; i < d->n_dirichlet; ++i) { const int32_t dof = d->dirichlet_dof[i]; if (dof < 0 || dof >= c->n_u) throw Error("dirichlet_dof out of range"); m[dof] = 1; v[dof] = d->dirichlet_value[i]; }
     c->dir_mask.upload(m); c->dir_val.upload(v);
+    { std::vector<uint8_t> nm((size_t)(c->n_u / c->dim), 0); for (int64_t i = 0; i < d->n_dirichlet; ++i) nm[d->dirichlet_dof[i] / c->dim] |= (uint8_t)(1u << (d->dirichlet_dof[i] % c->dim)); c->node_mask.upload(nm); }
+    if (d->n_dirichlet) c->dir_dofs.upload(d->dirichlet_dof, d->n_dirichlet);
     if (d->box.enabled) {   // are all constrained dofs on the box boundary?  (lets the matrix-free kernels skip mask loads in the interior)
       int64_t nn[3] = {1, 1, 1}; for (int k = 0; k < c->dim; ++k) nn[k] = (int64_t)c->k_u * d->box.n[k] + 1;
       for (int64_t i = 0; i < d->n_dirichlet; ++i) {

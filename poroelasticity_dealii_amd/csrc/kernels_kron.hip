@@ -6,35 +6,44 @@
 //   A_aa = (lambda+2G) K_a (x) M (x) M + G sum_{d != a} K_d (x) M (x) M,   A_ab = lambda C_a (x) C_b^T (x) M + G C_a^T (x) C_b (x) M
 // (validated against the assembled matrix to 1e-15 in tools/kron_proto.py).  With C = O + D (off-diagonal part + boundary
 // diagonal) and C^T = -O + D, one application is 9 z-sweeps + 15 y-sweeps + 9 x-sweeps of <= 5-point 1D stencils:
-// ~160 FMA per node instead of ~800 for the element-matrix gather, which turns the kernel from FP64-issue-bound into HBM-bound.
+// ~180 flop-instructions per node instead of ~800 FMAs for the element-matrix gather.
 //
-// Mapping: a workgroup owns a 60 x 12 node column of the mesh (64 x 16 with halo) and MARCHES along z over a chunk of planes.
-//   z: each thread keeps a 5-plane window of its nodes in registers (sliding, planes processed in vertex/mid pairs);
-//   y: the nine z-stage fields of a plane go through LDS; waves hold rows of ONE parity so band coefficients are SGPRs;
-//   x: a thread owns an (even, odd) node pair; contributions to the neighbour pairs travel by wave shuffles (scatter form).
-// Out-of-domain nodes are loaded as zeros, so only the centre coefficients know about the domain boundary.
-// No atomics; results are bitwise reproducible.  Dirichlet rows/columns handled as in k_mf_apply.
+// Mapping: a 1024-thread workgroup owns a 60 x 12 node column of the mesh (64 x 16 with halo) and MARCHES along z over a chunk
+// of planes; one thread per node, one tile row per wavefront (~100 VGPRs -> 4 waves per SIMD to hide latencies).
+//   z: each thread keeps a 5-plane window of its node in registers (sliding, planes processed in vertex/mid pairs);
+//   y: the nine z-stage fields of a plane go through LDS (8 B per lane, conflict-free); a wave holds ONE row, so the row
+//      parity and with it every band coefficient is wave-uniform (inline constants, no divergence);
+//   x: lanes are consecutive nodes; contributions to the nodes at +-1, +-2 travel by wave shuffles (scatter form).
+// Rows are dealt to waves so that the four waves sharing a SIMD carry equal work (vertex rows cost more than mid rows,
+// halo rows only run the z-stage).  Out-of-domain nodes are loaded as zeros, so only the centre coefficients know about
+// the domain boundary.  No atomics; results are bitwise reproducible.  Dirichlet rows / columns handled as in k_mf_apply.
 #include "common.hpp"
 
 namespace poro {
 namespace {
 
-constexpr int TXL = 32;          // x-pairs per row of the tile (64 nodes, 60 valid)
-constexpr int TYR = 16;          // rows of the tile (12 valid)
+constexpr int TXN = 64;          // nodes per row of the tile = lanes of a wave (60 valid)
+constexpr int TYR = 16;          // rows of the tile = waves of the workgroup (12 valid)
 constexpr int NFLD = 12;         // 9 z-stage fields + 3 boundary-plane fields
 constexpr int VX = 60, VY = 12;  // valid outputs per tile
 
-struct D2 { double e, o; };
-__device__ inline D2 operator*(double s, D2 v) { return {s * v.e, s * v.o}; }
-__device__ inline D2 operator+(D2 a, D2 b) { return {a.e + b.e, a.o + b.o}; }
-__device__ inline void fma2(D2 &acc, double s, D2 v) { acc.e = fma(s, v.e, acc.e); acc.o = fma(s, v.o, acc.o); }
-
-struct Kron1D { double M[3][3], K[3][3], C[3][3]; };
+// FE_Q(2) 1D element matrices on a cell of length h are small-integer matrices times a scale:
+//   M = (h/30) [[4,2,-1],[2,16,2],[-1,2,4]],  K = (1/3h) [[7,-8,1],[-8,16,-8],[1,-8,7]],  C = (1/6) [[-3,-4,1],[4,0,-4],[-1,4,3]]
+// (checked against Gauss quadrature of the Lagrange basis, check_q2_element_matrices).  Assembled rows:
+//   vertex row: M (-1, 2, cM, 2, -1)  K (1, -8, cK, -8, 1)  O (-1, 4, ., -4, 1)  D = cD;  cM = 4(mL+mR), cK = 7(mL+mR), cD = 3(mL-mR)
+//   mid row:    M (2, 16, 2)          K (-8, 16, -8)        O (4, ., -4)         D = 0        (mL / mR: left / right cell exists)
+// so every band coefficient is an inline constant and all scales fold into the 18 uniform constants below.
+struct KronConsts {
+  double xk_l2g, xk_g;                         // (lambda+2G | G) sMy sKx sMz                                   -> XK
+  double m_gKyMz, m_gMyKz, m_lKyMz, m_lMyKz;   // G sKy sMx sMz, G sMy sMx sKz, (l+2G) sKy sMx sMz, (l+2G) sMy sMx sKz   -> XM
+  double cc_mz[4];                             // c1..c4 * sC sC sMz   (O_y / D_y of mz      -> XO, XD)
+  double cc_oz[4];                             // c1..c4 * sMy sC sC   (M_y of oz / wz        -> XO, XD)
+  double cc_mx[4];                             // c1..c4 * sC sMx sC   (O_y / D_y of oz / wz  -> XM)
+};
 struct KronArgs {
   int nn[3]; int ntx, nty, nzc, chunk;   // chunk = planes per z-chunk (even)
-  Kron1D e[3];
-  double lam, G;
-  const uint8_t *mask; const double *diag_local; int constrained, mask_anywhere;
+  KronConsts k;
+  const uint8_t *nodemask; int constrained, mask_anywhere;
 };
 
 __device__ inline int64_t xcd_remap(int64_t bid, int64_t n) {
@@ -42,10 +51,9 @@ __device__ inline int64_t xcd_remap(int64_t bid, int64_t n) {
   return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(1024)
 k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
-  extern __shared__ double lds_raw[];
-  D2 *L = reinterpret_cast<D2 *>(lds_raw);                 // [NFLD][TYR][TXL]
+  extern __shared__ double L[];                            // [NFLD][TYR][TXN]
   const int tid = threadIdx.x;
   const int NX = a.nn[0], NY = a.nn[1], NZ = a.nn[2];
   const int64_t nblocks = (int64_t)a.ntx * a.nty * a.nzc;
@@ -54,188 +62,162 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   const int X0 = VX * txi - 2, Y0 = VY * tyi - 2;
   const int k0 = zc * a.chunk, k1 = min(NZ, k0 + a.chunk);
 
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, rw = lane >> 5, px = lane & 31;
-  // rows of one parity per wave; waves 0,1 hold the halo rows (0,14) / (1,15) and only feed the y-stage of the others
-  const int r = (w < 2) ? (w + 14 * rw) : (4 * ((w - 2) >> 1) + 2 + (w & 1) + 2 * rw);
-  const bool odd_row = (w & 1) != 0, halo_wave = w < 2;
-  const int j = Y0 + r, ie = X0 + 2 * px, io = ie + 1;
-  const bool vj = j >= 0 && j < NY, ve = vj && ie >= 0 && ie < NX, vo = vj && io >= 0 && io < NX;
-  const bool out_e = ve && px >= 1 && px <= 30 && r >= 2 && r <= 13, out_o = vo && px >= 1 && px <= 30 && r >= 2 && r <= 13;
-  const bool bnd_xy_e = ie == 0 || ie == NX - 1 || j == 0 || j == NY - 1, bnd_xy_o = j == 0 || j == NY - 1;   // odd nodes are never on an x face
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // waves w, w+4, w+8, w+12 share a SIMD: give each SIMD 1-2 vertex rows, 1-2 mid rows and one halo row
+  const int r = (w < 4) ? 2 + 2 * w : (w < 8) ? 3 + 2 * (w - 4) : (w < 12) ? w + 2 : (w == 12 ? 1 : w == 13 ? 0 : w == 14 ? 15 : 14);
+  const bool odd_row = (r & 1) != 0, halo_wave = r < 2 || r > 13;
+  const int j = Y0 + r, i = X0 + lane;
+  const bool even_i = (lane & 1) == 0;
+  const bool vj = j >= 0 && j < NY, vn = vj && i >= 0 && i < NX;
+  const bool out = vn && lane >= 2 && lane <= 61 && !halo_wave;
+  const bool bnd_xy = i == 0 || i == NX - 1 || j == 0 || j == NY - 1;
 
-  const Kron1D &EX = a.e[0], &EY = a.e[1], &EZ = a.e[2];
-  // centre coefficients (the only place the domain boundary enters): vertex rows sum the parts of the cells that exist
-  const double cMx = (ie > 0 ? EX.M[2][2] : 0.0) + (ie < NX - 1 ? EX.M[0][0] : 0.0);
-  const double cKx = (ie > 0 ? EX.K[2][2] : 0.0) + (ie < NX - 1 ? EX.K[0][0] : 0.0);
-  const double cDx = (ie > 0 ? EX.C[2][2] : 0.0) + (ie < NX - 1 ? EX.C[0][0] : 0.0);
-  const double cMy = odd_row ? EY.M[1][1] : (j > 0 ? EY.M[2][2] : 0.0) + (j < NY - 1 ? EY.M[0][0] : 0.0);
-  const double cKy = odd_row ? EY.K[1][1] : (j > 0 ? EY.K[2][2] : 0.0) + (j < NY - 1 ? EY.K[0][0] : 0.0);
-  const double cDy = odd_row ? EY.C[1][1] : (j > 0 ? EY.C[2][2] : 0.0) + (j < NY - 1 ? EY.C[0][0] : 0.0);
+  // centre coefficients (the only place the domain boundary enters); pe switches the +-2 messages off for mid nodes
+  const double mLx = i > 0 ? 1.0 : 0.0, mRx = i < NX - 1 ? 1.0 : 0.0, mLy = j > 0 ? 1.0 : 0.0, mRy = j < NY - 1 ? 1.0 : 0.0;
+  const double pe = even_i ? 1.0 : 0.0;
+  const double cMx = even_i ? 4.0 * (mLx + mRx) : 16.0, cKx = even_i ? 7.0 * (mLx + mRx) : 16.0, cDx = even_i ? 3.0 * (mLx - mRx) : 0.0;
+  const double cMy = odd_row ? 16.0 : 4.0 * (mLy + mRy), cKy = odd_row ? 16.0 : 7.0 * (mLy + mRy), cDy = odd_row ? 0.0 : 3.0 * (mLy - mRy);
+  const KronConsts &K = a.k;
 
-  const double lam = a.lam, G = a.G, l2g = lam + 2 * G, c1 = -(lam + G), c2 = lam - G, c3 = G - lam, c4 = lam + G;
-
-  auto load_plane = [&](int p, double (&v)[6]) {
+  // loads are asynchronous: the node's constraint bits (bit c = dof (node,c) is a Dirichlet dof) travel with the values and are
+  // applied only when the plane enters the window, so no wait on the in-flight prefetch is ever forced early
+  auto load_plane = [&](int p, double (&v)[3], unsigned &m) {
+    v[0] = v[1] = v[2] = 0.0; m = 0;
+    if (p < 0 || p >= NZ || !vn) return;
+    const int64_t node = ((int64_t)p * NY + j) * NX + i;
+    v[0] = x[node * 3]; v[1] = x[node * 3 + 1]; v[2] = x[node * 3 + 2];
+    if (a.constrained && (a.mask_anywhere || p == 0 || p == NZ - 1 || bnd_xy)) m = a.nodemask[node];
+  };
+  auto apply_mask = [&](double (&v)[3], unsigned m) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) v[c] = 0.0;
-    if (p < 0 || p >= NZ || !vj) return;
-    const int64_t base = ((int64_t)p * NY + j) * NX;
-    const bool zb = p == 0 || p == NZ - 1;
-    if (ve) {
-      const int64_t d0 = (base + ie) * 3;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = x[d0 + c];
-      if (a.constrained && (a.mask_anywhere || zb || bnd_xy_e)) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) if (a.mask[d0 + c]) v[c] = 0.0;
-      }
-    }
-    if (vo) {
-      const int64_t d0 = (base + io) * 3;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) v[3 + c] = x[d0 + c];
-      if (a.constrained && (a.mask_anywhere || zb || bnd_xy_o)) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) if (a.mask[d0 + c]) v[3 + c] = 0.0;
-      }
-    }
+    for (int c = 0; c < 3; ++c) if (m & (1u << c)) v[c] = 0.0;
   };
 
-  double W0[6], W1[6], W2[6], W3[6], W4[6], P0[6], P1[6];
-  load_plane(k0 - 2, W0); load_plane(k0 - 1, W1); load_plane(k0, W2); load_plane(k0 + 1, W3); load_plane(k0 + 2, W4);
+  double W0[3], W1[3], W2[3], W3[3], W4[3];
+  unsigned m0, m1, m2, m3, m4;
+  load_plane(k0 - 2, W0, m0); load_plane(k0 - 1, W1, m1); load_plane(k0, W2, m2); load_plane(k0 + 1, W3, m3); load_plane(k0 + 2, W4, m4);
+  apply_mask(W0, m0); apply_mask(W1, m1); apply_mask(W2, m2); apply_mask(W3, m3); apply_mask(W4, m4);
 
   // one plane: z-stage in registers -> LDS -> y-stage -> x-stage -> store
-  auto plane = [&](const int kk, const bool oddz) {
-    D2 f[9];       // mz_x mz_y mz_z kz_x kz_y kz_z oz_x oz_y oz_z
-    D2 wz[3];
+  auto plane = [&](const int kk, const bool oddz, auto &&after_zstage) {
+    double f[9];       // mz_x mz_y mz_z kz_x kz_y kz_z oz_x oz_y oz_z   (unscaled: integer band coefficients)
+    double wz[3];
     const bool has_w = !oddz && (kk == 0 || kk == NZ - 1);
     if (!oddz) {
-      const double cM = (kk > 0 ? EZ.M[2][2] : 0.0) + (kk < NZ - 1 ? EZ.M[0][0] : 0.0);
-      const double cK = (kk > 0 ? EZ.K[2][2] : 0.0) + (kk < NZ - 1 ? EZ.K[0][0] : 0.0);
-      const double cD = (kk > 0 ? EZ.C[2][2] : 0.0) + (kk < NZ - 1 ? EZ.C[0][0] : 0.0);
+      const double mL = kk > 0 ? 1.0 : 0.0, mR = kk < NZ - 1 ? 1.0 : 0.0;
+      const double cM = 4.0 * (mL + mR), cK = 7.0 * (mL + mR), cD = 3.0 * (mL - mR);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        f[c].e = EZ.M[2][0] * W0[c] + EZ.M[2][1] * W1[c] + cM * W2[c] + EZ.M[0][1] * W3[c] + EZ.M[0][2] * W4[c];
-        f[c].o = EZ.M[2][0] * W0[3 + c] + EZ.M[2][1] * W1[3 + c] + cM * W2[3 + c] + EZ.M[0][1] * W3[3 + c] + EZ.M[0][2] * W4[3 + c];
-        f[3 + c].e = EZ.K[2][0] * W0[c] + EZ.K[2][1] * W1[c] + cK * W2[c] + EZ.K[0][1] * W3[c] + EZ.K[0][2] * W4[c];
-        f[3 + c].o = EZ.K[2][0] * W0[3 + c] + EZ.K[2][1] * W1[3 + c] + cK * W2[3 + c] + EZ.K[0][1] * W3[3 + c] + EZ.K[0][2] * W4[3 + c];
-        f[6 + c].e = EZ.C[2][0] * W0[c] + EZ.C[2][1] * W1[c] + EZ.C[0][1] * W3[c] + EZ.C[0][2] * W4[c];
-        f[6 + c].o = EZ.C[2][0] * W0[3 + c] + EZ.C[2][1] * W1[3 + c] + EZ.C[0][1] * W3[3 + c] + EZ.C[0][2] * W4[3 + c];
-        wz[c].e = cD * W2[c]; wz[c].o = cD * W2[3 + c];
+        const double s1 = W1[c] + W3[c], s2 = W0[c] + W4[c];
+        f[c] = fma(cM, W2[c], fma(2.0, s1, -s2));
+        f[3 + c] = fma(cK, W2[c], fma(-8.0, s1, s2));
+        f[6 + c] = fma(4.0, W1[c] - W3[c], W4[c] - W0[c]);
+        wz[c] = cD * W2[c];
       }
     } else {   // mid plane: couples to kk-1, kk, kk+1 = W2, W3, W4
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        f[c].e = EZ.M[1][0] * W2[c] + EZ.M[1][1] * W3[c] + EZ.M[1][2] * W4[c];
-        f[c].o = EZ.M[1][0] * W2[3 + c] + EZ.M[1][1] * W3[3 + c] + EZ.M[1][2] * W4[3 + c];
-        f[3 + c].e = EZ.K[1][0] * W2[c] + EZ.K[1][1] * W3[c] + EZ.K[1][2] * W4[c];
-        f[3 + c].o = EZ.K[1][0] * W2[3 + c] + EZ.K[1][1] * W3[3 + c] + EZ.K[1][2] * W4[3 + c];
-        f[6 + c].e = EZ.C[1][0] * W2[c] + EZ.C[1][2] * W4[c];
-        f[6 + c].o = EZ.C[1][0] * W2[3 + c] + EZ.C[1][2] * W4[3 + c];
-        wz[c].e = EZ.C[1][1] * W3[c]; wz[c].o = EZ.C[1][1] * W3[3 + c];   // = 0 for Lagrange Q2
+        const double s1 = W2[c] + W4[c];
+        f[c] = fma(16.0, W3[c], 2.0 * s1);
+        f[3 + c] = fma(16.0, W3[c], -8.0 * s1);
+        f[6 + c] = 4.0 * (W2[c] - W4[c]);
+        wz[c] = 0.0;
       }
     }
+    after_zstage();                                    // (the even plane issues the prefetch of the next pair here: W0, W1 are dead now)
     __syncthreads();                                   // every wave is done reading the previous plane's fields
 #pragma unroll
-    for (int q = 0; q < 9; ++q) L[(q * TYR + r) * TXL + px] = f[q];
+    for (int q = 0; q < 9; ++q) L[(q * TYR + r) * TXN + lane] = f[q];
     if (has_w) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) L[((9 + c) * TYR + r) * TXL + px] = wz[c];
+      for (int c = 0; c < 3; ++c) L[((9 + c) * TYR + r) * TXN + lane] = wz[c];
     }
     __syncthreads();
     if (halo_wave) return;
 
-    // ---- y-stage: banded sweeps over the rows of the tile ----
-    // band coefficients of this wave's row parity (wave-uniform -> SGPR)
-    const double yMm2 = EY.M[2][0], yMm1 = odd_row ? EY.M[1][0] : EY.M[2][1], yMp1 = odd_row ? EY.M[1][2] : EY.M[0][1], yMp2 = EY.M[0][2];
-    const double yKm2 = EY.K[2][0], yKm1 = odd_row ? EY.K[1][0] : EY.K[2][1], yKp1 = odd_row ? EY.K[1][2] : EY.K[0][1], yKp2 = EY.K[0][2];
-    const double yOm2 = EY.C[2][0], yOm1 = odd_row ? EY.C[1][0] : EY.C[2][1], yOp1 = odd_row ? EY.C[1][2] : EY.C[0][1], yOp2 = EY.C[0][2];
-    D2 nm2, nm1, np1, np2;
+    // ---- y-stage: banded sweeps over the rows of the tile (row parity is wave-uniform) ----
+    double s1, s2, d1, d2, own;   // v(-1)+v(+1), v(-2)+v(+2), v(-1)-v(+1), v(+2)-v(-2), v(0)  (all re-read from LDS: the z-stage registers are dead)
     auto nb = [&](int q) {
-      nm1 = L[(q * TYR + r - 1) * TXL + px]; np1 = L[(q * TYR + r + 1) * TXL + px];
-      if (!odd_row) { nm2 = L[(q * TYR + r - 2) * TXL + px]; np2 = L[(q * TYR + r + 2) * TXL + px]; }
+      const double *col = L + (q * TYR + r) * TXN + lane;
+      const double nm1 = col[-TXN], np1 = col[TXN];
+      own = col[0];
+      s1 = nm1 + np1; d1 = nm1 - np1;
+      if (!odd_row) { const double nm2 = col[-2 * TXN], np2 = col[2 * TXN]; s2 = nm2 + np2; d2 = np2 - nm2; }
     };
-    auto sweepM = [&](D2 own) { D2 s = cMy * own; fma2(s, yMm1, nm1); fma2(s, yMp1, np1); if (!odd_row) { fma2(s, yMm2, nm2); fma2(s, yMp2, np2); } return s; };
-    auto sweepK = [&](D2 own) { D2 s = cKy * own; fma2(s, yKm1, nm1); fma2(s, yKp1, np1); if (!odd_row) { fma2(s, yKm2, nm2); fma2(s, yKp2, np2); } return s; };
-    auto sweepO = [&]() { D2 s = yOm1 * nm1; fma2(s, yOp1, np1); if (!odd_row) { fma2(s, yOm2, nm2); fma2(s, yOp2, np2); } return s; };
+    auto sweepM = [&]() { double s = fma(2.0, s1, cMy * own); if (!odd_row) s -= s2; return s; };
+    auto sweepK = [&]() { double s = fma(-8.0, s1, cKy * own); if (!odd_row) s += s2; return s; };
+    auto sweepO = [&]() { double s = 4.0 * d1; if (!odd_row) s += d2; return s; };
 
-    D2 XK[3], XM[3], XO[3], XD[3];
-    { nb(0); const D2 My = sweepM(f[0]), Ky = sweepK(f[0]), Oy = sweepO(), Dy = cDy * f[0];   // mz_x
-      XK[0] = l2g * My; XM[0] = G * Ky; XO[1] = c1 * Oy + c3 * Dy; XD[1] = c2 * Oy + c4 * Dy; }
-    { nb(1); const D2 My = sweepM(f[1]), Ky = sweepK(f[1]), Oy = sweepO(), Dy = cDy * f[1];   // mz_y
-      XK[1] = G * My; XM[1] = l2g * Ky; XO[0] = c1 * Oy + c2 * Dy; XD[0] = c3 * Oy + c4 * Dy; }
-    { nb(2); const D2 My = sweepM(f[2]), Ky = sweepK(f[2]);                                    // mz_z
-      XK[2] = G * My; XM[2] = G * Ky; }
-    { nb(3); fma2(XM[0], G, sweepM(f[3])); }                                                   // kz_x
-    { nb(4); fma2(XM[1], G, sweepM(f[4])); }                                                   // kz_y
-    { nb(5); fma2(XM[2], l2g, sweepM(f[5])); }                                                 // kz_z
-    { nb(6); const D2 My = sweepM(f[6]); XO[2] = c1 * My; XD[2] = c2 * My; }                   // oz_x
-    { nb(7); const D2 Oy = sweepO(), Dy = cDy * f[7]; fma2(XM[2], c1, Oy); fma2(XM[2], c2, Dy); }   // oz_y
-    { nb(8); const D2 My = sweepM(f[8]), Oy = sweepO(), Dy = cDy * f[8];                       // oz_z
-      fma2(XO[0], c1, My); fma2(XD[0], c3, My); fma2(XM[1], c1, Oy); fma2(XM[1], c3, Dy); }
+    double XK[3], XM[3], XO[3], XD[3];
+    { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_x
+      XK[0] = K.xk_l2g * My; XM[0] = K.m_gKyMz * Ky; XO[1] = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD[1] = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
+    { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_y
+      XK[1] = K.xk_g * My; XM[1] = K.m_lKyMz * Ky; XO[0] = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD[0] = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
+    { nb(2); const double My = sweepM(), Ky = sweepK();                                    // mz_z
+      XK[2] = K.xk_g * My; XM[2] = K.m_gKyMz * Ky; }
+    { nb(3); XM[0] = fma(K.m_gMyKz, sweepM(), XM[0]); }                                       // kz_x
+    { nb(4); XM[1] = fma(K.m_gMyKz, sweepM(), XM[1]); }                                       // kz_y
+    { nb(5); XM[2] = fma(K.m_lMyKz, sweepM(), XM[2]); }                                       // kz_z
+    { nb(6); const double My = sweepM(); XO[2] = K.cc_oz[0] * My; XD[2] = K.cc_oz[1] * My; }  // oz_x
+    { nb(7); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[1], Dy, XM[2])); }   // oz_y
+    { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                      // oz_z
+      XO[0] = fma(K.cc_oz[0], My, XO[0]); XD[0] = fma(K.cc_oz[2], My, XD[0]); XM[1] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM[1])); }
     if (has_w) {   // first / last plane: the boundary diagonal of C_z
-      { nb(9); const D2 My = sweepM(wz[0]); fma2(XO[2], c3, My); fma2(XD[2], c4, My); }                                      // wz_x
-      { nb(10); const D2 Oy = sweepO(), Dy = cDy * wz[1]; fma2(XM[2], c3, Oy); fma2(XM[2], c4, Dy); }                         // wz_y
-      { nb(11); const D2 My = sweepM(wz[2]), Oy = sweepO(), Dy = cDy * wz[2];                                                 // wz_z
-        fma2(XO[0], c2, My); fma2(XD[0], c4, My); fma2(XM[1], c2, Oy); fma2(XM[1], c4, Dy); }
+      { nb(9); const double My = sweepM(); XO[2] = fma(K.cc_oz[2], My, XO[2]); XD[2] = fma(K.cc_oz[3], My, XD[2]); }            // wz_x
+      { nb(10); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[2], Oy, fma(K.cc_mx[3], Dy, XM[2])); }             // wz_y
+      { nb(11); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                                                    // wz_z
+        XO[0] = fma(K.cc_oz[1], My, XO[0]); XD[0] = fma(K.cc_oz[3], My, XD[0]); XM[1] = fma(K.cc_mx[1], Oy, fma(K.cc_mx[3], Dy, XM[1])); }
     }
 
-    // ---- x-stage, scatter form: own-pair terms + three messages per component through wave shuffles ----
-    double ye[3], yo[3];
+    // ---- x-stage, scatter form: the node's own term + messages to the nodes at +-1 and (vertex nodes only) +-2 ----
+    double yv[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const D2 FK = XK[c], FM = XM[c], FO = XO[c], FD = XD[c];
-      double se = cKx * FK.e + EX.K[0][1] * FK.o + cMx * FM.e + EX.M[0][1] * FM.o + EX.C[0][1] * FO.o + cDx * FD.e;
-      double so = EX.K[1][0] * FK.e + EX.K[1][1] * FK.o + EX.M[1][0] * FM.e + EX.M[1][1] * FM.o + EX.C[1][0] * FO.e + EX.C[1][1] * FD.o;
-      const double toR = EX.K[2][0] * FK.e + EX.K[2][1] * FK.o + EX.M[2][0] * FM.e + EX.M[2][1] * FM.o + EX.C[2][0] * FO.e + EX.C[2][1] * FO.o;   // row i+2 (vertex), its left cell
-      const double toLe = EX.K[0][2] * FK.e + EX.M[0][2] * FM.e + EX.C[0][2] * FO.e;   // row i-2 (vertex), its right cell
-      const double toLo = EX.K[1][2] * FK.e + EX.M[1][2] * FM.e + EX.C[1][2] * FO.e;   // row i-1 (mid)
-      se += __shfl_up(toR, 1, 32) + __shfl_down(toLe, 1, 32);
-      so += __shfl_down(toLo, 1, 32);
-      ye[c] = se; yo[c] = so;
+      const double FK = XK[c], FM = XM[c], FO = XO[c], FD = XD[c];
+      const double t1 = fma(-8.0, FK, 2.0 * FM);         // K / M part of the +-1 coupling (the same for vertex and mid sources)
+      const double t2 = pe * (FK - FM);                  // +-2 coupling exists only between vertex nodes
+      const double pO = pe * FO;
+      double s = fma(cKx, FK, fma(cMx, FM, cDx * FD));
+      s += __shfl_up(fma(4.0, FO, t1), 1) + __shfl_down(fma(-4.0, FO, t1), 1);     // from i-1 (its +1 message) and i+1 (its -1 message)
+      s += __shfl_up(t2 - pO, 2) + __shfl_down(t2 + pO, 2);                        // from i-2 and i+2
+      yv[c] = s;
     }
-    const int64_t base = ((int64_t)kk * NY + j) * NX;
-    const bool zb = kk == 0 || kk == NZ - 1;
-    if (out_e) {
-      const int64_t d0 = (base + ie) * 3;
-      if (a.constrained && (a.mask_anywhere || zb || bnd_xy_e)) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) if (a.mask[d0 + c]) ye[c] = a.diag_local[d0 + c] * x[d0 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) y[d0 + c] = ye[c];
-    }
-    if (out_o) {
-      const int64_t d0 = (base + io) * 3;
-      if (a.constrained && (a.mask_anywhere || zb || bnd_xy_o)) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) if (a.mask[d0 + c]) yo[c] = a.diag_local[d0 + c] * x[d0 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) y[d0 + c] = yo[c];
+    if (out) {   // constrained rows are rewritten by k_kron_fix_constrained afterwards
+      const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
+      y[d0] = yv[0]; y[d0 + 1] = yv[1]; y[d0 + 2] = yv[2];
     }
   };
 
   for (int k = k0; k < k1; k += 2) {
-    load_plane(k + 3, P0); load_plane(k + 4, P1);       // prefetch the next pair while this one computes
-    plane(k, false);
-    if (k + 1 < k1) plane(k + 1, true);
+    plane(k, false, [&] { load_plane(k + 3, W0, m0); load_plane(k + 4, W1, m1); });   // planes k-2, k-1 are no longer needed
+    if (k + 1 < k1) plane(k + 1, true, [] {});
+    // rotate the window by two planes; the prefetched planes get their Dirichlet columns zeroed as they enter
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { W0[c] = W2[c]; W1[c] = W3[c]; W2[c] = W4[c]; W3[c] = P0[c]; W4[c] = P1[c]; }
+    for (int c = 0; c < 3; ++c) { const double t0 = W0[c], t1 = W1[c]; W0[c] = W2[c]; W1[c] = W3[c]; W2[c] = W4[c]; W3[c] = t0; W4[c] = t1; }
+    apply_mask(W3, m0); apply_mask(W4, m1);
   }
 }
 
-// 1D element matrices of FE_Q(2) on a cell of length h: M = h int phi_a phi_b, K = (1/h) int phi_a' phi_b', C = int phi_a' phi_b
-Kron1D make_1d(double h) {
-  // 4-point Gauss-Legendre on [0,1] (exact to degree 7)
+// y_i = diag_i x_i on the Dirichlet rows (ConstraintMatrix elimination), from the constraint list
+__global__ void k_kron_fix_constrained(int64_t n, const int32_t *__restrict__ dofs, const double *__restrict__ diag_local, const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) { const int32_t d = dofs[t]; y[d] = diag_local[d] * x[d]; }
+}
+
+// checks the integer element matrices above against Gauss quadrature of the Lagrange basis (4 points on [0,1], exact to degree 7)
+void check_q2_element_matrices() {
   const double gx[4] = {0.0694318442029737124, 0.3300094782075718676, 0.6699905217924281324, 0.9305681557970262876};
   const double gw[4] = {0.1739274225687269287, 0.3260725774312730713, 0.3260725774312730713, 0.1739274225687269287};
-  Kron1D e{};
+  const double Mi[3][3] = {{4, 2, -1}, {2, 16, 2}, {-1, 2, 4}}, Ki[3][3] = {{7, -8, 1}, {-8, 16, -8}, {1, -8, 7}}, Ci[3][3] = {{-3, -4, 1}, {4, 0, -4}, {-1, 4, 3}};
+  double M[3][3] = {{0}}, K[3][3] = {{0}}, C[3][3] = {{0}};
   for (int q = 0; q < 4; ++q) {
     const double t = gx[q];
     const double v[3] = {2 * (t - 0.5) * (t - 1), 4 * t * (1 - t), 2 * t * (t - 0.5)}, d[3] = {4 * t - 3, 4 - 8 * t, 4 * t - 1};
-    for (int i = 0; i < 3; ++i) for (int jj = 0; jj < 3; ++jj) { e.M[i][jj] += h * gw[q] * v[i] * v[jj]; e.K[i][jj] += gw[q] * d[i] * d[jj] / h; e.C[i][jj] += gw[q] * d[i] * v[jj]; }
+    for (int i = 0; i < 3; ++i) for (int jj = 0; jj < 3; ++jj) { M[i][jj] += gw[q] * v[i] * v[jj]; K[i][jj] += gw[q] * d[i] * d[jj]; C[i][jj] += gw[q] * d[i] * v[jj]; }
   }
-  return e;
+  for (int i = 0; i < 3; ++i) for (int jj = 0; jj < 3; ++jj)
+    if (std::fabs(30 * M[i][jj] - Mi[i][jj]) > 1e-12 || std::fabs(3 * K[i][jj] - Ki[i][jj]) > 1e-12 || std::fabs(6 * C[i][jj] - Ci[i][jj]) > 1e-12)
+      throw Error("Q2 1D element matrices do not match their integer form");
 }
 
 }  // namespace
@@ -243,19 +225,28 @@ Kron1D make_1d(double h) {
 bool kron_supported(int dim, int k_u) { return dim == 3 && k_u == 2; }
 
 void kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus) {
+  static bool checked = false;
+  if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
-  for (int d = 0; d < 3; ++d) { a.nn[d] = 2 * m.box.n[d] + 1; a.e[d] = make_1d(m.box.h[d]); }
+  for (int d = 0; d < 3; ++d) a.nn[d] = 2 * m.box.n[d] + 1;
   a.ntx = (a.nn[0] + VX - 1) / VX; a.nty = (a.nn[1] + VY - 1) / VY;
-  // z-chunks: enough workgroups to fill the chip (one 512-thread workgroup per CU), each chunk an even number of planes
+  // z-chunks: as many workgroups as fit the chip in ONE round (one 1024-thread workgroup per CU), an even number of planes each
   const int cols = a.ntx * a.nty;
-  int nzc = (n_cus + cols - 1) / cols; if (nzc < 1) nzc = 1;
+  int nzc = n_cus / cols; if (nzc < 1) nzc = 1;
   int chunk = (a.nn[2] + nzc - 1) / nzc; chunk += chunk & 1; if (chunk < 8) chunk = 8;
   a.chunk = chunk; a.nzc = (a.nn[2] + chunk - 1) / chunk;
-  a.lam = m.lam; a.G = m.G; a.mask = m.mask; a.diag_local = m.diag_local; a.constrained = constrained ? 1 : 0; a.mask_anywhere = m.mask_anywhere;
-  const size_t lds = (size_t)NFLD * TYR * TXL * sizeof(D2);
+  const double lam = m.lam, G = m.G, l2g = lam + 2 * G, c[4] = {-(lam + G), lam - G, G - lam, lam + G};
+  const double sM[3] = {m.box.h[0] / 30, m.box.h[1] / 30, m.box.h[2] / 30}, sK[3] = {1 / (3 * m.box.h[0]), 1 / (3 * m.box.h[1]), 1 / (3 * m.box.h[2])}, sC = 1.0 / 6;
+  KronConsts &k = a.k;
+  k.xk_l2g = l2g * sM[1] * sK[0] * sM[2]; k.xk_g = G * sM[1] * sK[0] * sM[2];
+  k.m_gKyMz = G * sK[1] * sM[0] * sM[2]; k.m_gMyKz = G * sM[1] * sM[0] * sK[2]; k.m_lKyMz = l2g * sK[1] * sM[0] * sM[2]; k.m_lMyKz = l2g * sM[1] * sM[0] * sK[2];
+  for (int i = 0; i < 4; ++i) { k.cc_mz[i] = c[i] * sC * sC * sM[2]; k.cc_oz[i] = c[i] * sM[1] * sC * sC; k.cc_mx[i] = c[i] * sC * sM[0] * sC; }
+  a.nodemask = m.nodemask; a.constrained = constrained ? 1 : 0; a.mask_anywhere = m.mask_anywhere;
+  const size_t lds = (size_t)NFLD * TYR * TXN * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) { PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-  hipLaunchKernelGGL(k_kron3_q2, (unsigned)(a.ntx * a.nty * a.nzc), 512, lds, s, a, x, y);
+  hipLaunchKernelGGL(k_kron3_q2, (unsigned)(a.ntx * a.nty * a.nzc), 1024, lds, s, a, x, y);
+  if (constrained && m.n_dirichlet) hipLaunchKernelGGL(k_kron_fix_constrained, (unsigned)((m.n_dirichlet + 255) / 256), 256, 0, s, m.n_dirichlet, m.dirichlet_dofs, m.diag_local, x, y);
 }
 
 }  // namespace poro
