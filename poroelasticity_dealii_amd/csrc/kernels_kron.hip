@@ -24,7 +24,7 @@ namespace {
 
 constexpr int TXN = 64;          // nodes per row of the tile = lanes of a wave (60 valid)
 constexpr int TYR = 16;          // rows of the tile = waves of the workgroup (12 valid)
-constexpr int NFLD = 12;         // 9 z-stage fields + 3 boundary-plane fields
+constexpr int NFLD = 18;         // two buffers of the 9 z-stage fields of a plane
 constexpr int VX = 60, VY = 12;  // valid outputs per tile
 
 // FE_Q(2) 1D element matrices on a cell of length h are small-integer matrices times a scale:
@@ -98,76 +98,86 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   load_plane(k0 - 2, W0, m0); load_plane(k0 - 1, W1, m1); load_plane(k0, W2, m2); load_plane(k0 + 1, W3, m3); load_plane(k0 + 2, W4, m4);
   apply_mask(W0, m0); apply_mask(W1, m1); apply_mask(W2, m2); apply_mask(W3, m3); apply_mask(W4, m4);
 
-  // one plane: z-stage in registers -> LDS -> y-stage -> x-stage -> store
-  auto plane = [&](const int kk, const bool oddz, auto &&after_zstage) {
-    double f[9];       // mz_x mz_y mz_z kz_x kz_y kz_z oz_x oz_y oz_z   (unscaled: integer band coefficients)
-    double wz[3];
-    const bool has_w = !oddz && (kk == 0 || kk == NZ - 1);
-    if (!oddz) {
-      const double mL = kk > 0 ? 1.0 : 0.0, mR = kk < NZ - 1 ? 1.0 : 0.0;
-      const double cM = 4.0 * (mL + mR), cK = 7.0 * (mL + mR), cD = 3.0 * (mL - mR);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double s1 = W1[c] + W3[c], s2 = W0[c] + W4[c];
-        f[c] = fma(cM, W2[c], fma(2.0, s1, -s2));
-        f[3 + c] = fma(cK, W2[c], fma(-8.0, s1, s2));
-        f[6 + c] = fma(4.0, W1[c] - W3[c], W4[c] - W0[c]);
-        wz[c] = cD * W2[c];
-      }
-    } else {   // mid plane: couples to kk-1, kk, kk+1 = W2, W3, W4
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double s1 = W2[c] + W4[c];
-        f[c] = fma(16.0, W3[c], 2.0 * s1);
-        f[3 + c] = fma(16.0, W3[c], -8.0 * s1);
-        f[6 + c] = 4.0 * (W2[c] - W4[c]);
-        wz[c] = 0.0;
-      }
-    }
-    after_zstage();                                    // (the even plane issues the prefetch of the next pair here: W0, W1 are dead now)
-    __syncthreads();                                   // every wave is done reading the previous plane's fields
-#pragma unroll
-    for (int q = 0; q < 9; ++q) L[(q * TYR + r) * TXN + lane] = f[q];
-    if (has_w) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) L[((9 + c) * TYR + r) * TXN + lane] = wz[c];
-    }
-    __syncthreads();
-    if (halo_wave) return;
+  // y-stage helpers: neighbours and the node's own value of field q come from the LDS buffer `Lb`
+  const double *Lb = L;
+  double s1, s2, d1, d2, own;   // v(-1)+v(+1), v(-2)+v(+2), v(-1)-v(+1), v(+2)-v(-2), v(0)
+  auto nb = [&](int q) {
+    const double *col = Lb + (q * TYR + r) * TXN + lane;
+    const double nm1 = col[-TXN], np1 = col[TXN];
+    own = col[0];
+    s1 = nm1 + np1; d1 = nm1 - np1;
+    if (!odd_row) { const double nm2 = col[-2 * TXN], np2 = col[2 * TXN]; s2 = nm2 + np2; d2 = np2 - nm2; }
+  };
+  auto sweepM = [&]() { double s = fma(2.0, s1, cMy * own); if (!odd_row) s -= s2; return s; };
+  auto sweepK = [&]() { double s = fma(-8.0, s1, cKy * own); if (!odd_row) s += s2; return s; };
+  auto sweepO = [&]() { double s = 4.0 * d1; if (!odd_row) s += d2; return s; };
 
-    // ---- y-stage: banded sweeps over the rows of the tile (row parity is wave-uniform) ----
-    double s1, s2, d1, d2, own;   // v(-1)+v(+1), v(-2)+v(+2), v(-1)-v(+1), v(+2)-v(-2), v(0)  (all re-read from LDS: the z-stage registers are dead)
-    auto nb = [&](int q) {
-      const double *col = L + (q * TYR + r) * TXN + lane;
-      const double nm1 = col[-TXN], np1 = col[TXN];
-      own = col[0];
-      s1 = nm1 + np1; d1 = nm1 - np1;
-      if (!odd_row) { const double nm2 = col[-2 * TXN], np2 = col[2 * TXN]; s2 = nm2 + np2; d2 = np2 - nm2; }
-    };
-    auto sweepM = [&]() { double s = fma(2.0, s1, cMy * own); if (!odd_row) s -= s2; return s; };
-    auto sweepK = [&]() { double s = fma(-8.0, s1, cKy * own); if (!odd_row) s += s2; return s; };
-    auto sweepO = [&]() { double s = 4.0 * d1; if (!odd_row) s += d2; return s; };
+  // one plane: z-stage in registers -> LDS (double buffered: ONE barrier per plane) -> y-stage -> x-stage -> store
+  int buf = 0;
+  auto plane = [&](const int kk, const bool oddz, auto &&after_zstage) {
+    double *Lw = L + buf * (9 * TYR * TXN);
+    {
+      double f[9];       // mz_x mz_y mz_z kz_x kz_y kz_z oz_x oz_y oz_z   (unscaled: integer band coefficients)
+      if (!oddz) {
+        const double mL = kk > 0 ? 1.0 : 0.0, mR = kk < NZ - 1 ? 1.0 : 0.0;
+        const double cM = 4.0 * (mL + mR), cK = 7.0 * (mL + mR);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double t1 = W1[c] + W3[c], t2 = W0[c] + W4[c];
+          f[c] = fma(cM, W2[c], fma(2.0, t1, -t2));
+          f[3 + c] = fma(cK, W2[c], fma(-8.0, t1, t2));
+          f[6 + c] = fma(4.0, W1[c] - W3[c], W4[c] - W0[c]);
+        }
+      } else {   // mid plane: couples to kk-1, kk, kk+1 = W2, W3, W4
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double t1 = W2[c] + W4[c];
+          f[c] = fma(16.0, W3[c], 2.0 * t1);
+          f[3 + c] = fma(16.0, W3[c], -8.0 * t1);
+          f[6 + c] = 4.0 * (W2[c] - W4[c]);
+        }
+      }
+      // safe without a barrier: every wave passed the previous barrier only after it finished reading this buffer two planes ago
+#pragma unroll
+      for (int q = 0; q < 9; ++q) Lw[(q * TYR + r) * TXN + lane] = f[q];
+    }
+    const bool has_w = !oddz && (kk == 0 || kk == NZ - 1);   // workgroup-uniform
+    double wz[3];
+    if (has_w) { const double cD = 3.0 * ((kk > 0 ? 1.0 : 0.0) - (kk < NZ - 1 ? 1.0 : 0.0)); wz[0] = cD * W2[0]; wz[1] = cD * W2[1]; wz[2] = cD * W2[2]; }
+    after_zstage();                                    // (the even plane issues the prefetch of the next pair here: W0, W1 are dead now)
+    __syncthreads();
+    Lb = Lw; buf ^= 1;
 
     double XK[3], XM[3], XO[3], XD[3];
-    { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_x
-      XK[0] = K.xk_l2g * My; XM[0] = K.m_gKyMz * Ky; XO[1] = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD[1] = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
-    { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_y
-      XK[1] = K.xk_g * My; XM[1] = K.m_lKyMz * Ky; XO[0] = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD[0] = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
-    { nb(2); const double My = sweepM(), Ky = sweepK();                                    // mz_z
-      XK[2] = K.xk_g * My; XM[2] = K.m_gKyMz * Ky; }
-    { nb(3); XM[0] = fma(K.m_gMyKz, sweepM(), XM[0]); }                                       // kz_x
-    { nb(4); XM[1] = fma(K.m_gMyKz, sweepM(), XM[1]); }                                       // kz_y
-    { nb(5); XM[2] = fma(K.m_lMyKz, sweepM(), XM[2]); }                                       // kz_z
-    { nb(6); const double My = sweepM(); XO[2] = K.cc_oz[0] * My; XD[2] = K.cc_oz[1] * My; }  // oz_x
-    { nb(7); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[1], Dy, XM[2])); }   // oz_y
-    { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                      // oz_z
-      XO[0] = fma(K.cc_oz[0], My, XO[0]); XD[0] = fma(K.cc_oz[2], My, XD[0]); XM[1] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM[1])); }
-    if (has_w) {   // first / last plane: the boundary diagonal of C_z
-      { nb(9); const double My = sweepM(); XO[2] = fma(K.cc_oz[2], My, XO[2]); XD[2] = fma(K.cc_oz[3], My, XD[2]); }            // wz_x
-      { nb(10); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[2], Oy, fma(K.cc_mx[3], Dy, XM[2])); }             // wz_y
-      { nb(11); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                                                    // wz_z
-        XO[0] = fma(K.cc_oz[1], My, XO[0]); XD[0] = fma(K.cc_oz[3], My, XD[0]); XM[1] = fma(K.cc_mx[1], Oy, fma(K.cc_mx[3], Dy, XM[1])); }
+    if (!halo_wave) {
+      { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_x
+        XK[0] = K.xk_l2g * My; XM[0] = K.m_gKyMz * Ky; XO[1] = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD[1] = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
+      { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_y
+        XK[1] = K.xk_g * My; XM[1] = K.m_lKyMz * Ky; XO[0] = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD[0] = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
+      { nb(2); const double My = sweepM(), Ky = sweepK();                                    // mz_z
+        XK[2] = K.xk_g * My; XM[2] = K.m_gKyMz * Ky; }
+      { nb(3); XM[0] = fma(K.m_gMyKz, sweepM(), XM[0]); }                                    // kz_x
+      { nb(4); XM[1] = fma(K.m_gMyKz, sweepM(), XM[1]); }                                    // kz_y
+      { nb(5); XM[2] = fma(K.m_lMyKz, sweepM(), XM[2]); }                                    // kz_z
+      { nb(6); const double My = sweepM(); XO[2] = K.cc_oz[0] * My; XD[2] = K.cc_oz[1] * My; }   // oz_x
+      { nb(7); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[1], Dy, XM[2])); }   // oz_y
+      { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                    // oz_z
+        XO[0] = fma(K.cc_oz[0], My, XO[0]); XD[0] = fma(K.cc_oz[2], My, XD[0]); XM[1] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM[1])); }
     }
+    if (has_w) {   // first / last plane of the box: the boundary diagonal D_z of C_z, wz = cD u, through slots 0..2 of the same buffer
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Lw[(c * TYR + r) * TXN + lane] = wz[c];
+      __syncthreads();
+      if (!halo_wave) {
+        { nb(0); const double My = sweepM(); XO[2] = fma(K.cc_oz[2], My, XO[2]); XD[2] = fma(K.cc_oz[3], My, XD[2]); }            // wz_x
+        { nb(1); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[2], Oy, fma(K.cc_mx[3], Dy, XM[2])); }           // wz_y
+        { nb(2); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                                                       // wz_z
+          XO[0] = fma(K.cc_oz[1], My, XO[0]); XD[0] = fma(K.cc_oz[3], My, XD[0]); XM[1] = fma(K.cc_mx[1], Oy, fma(K.cc_mx[3], Dy, XM[1])); }
+      }
+      __syncthreads();   // slots 0..2 must not be overwritten by a fast wave's plane kk+2 before everybody has read wz (same buffer)
+    }
+    if (halo_wave) return;
 
     // ---- x-stage, scatter form: the node's own term + messages to the nodes at +-1 and (vertex nodes only) +-2 ----
     double yv[3];
