@@ -167,6 +167,15 @@ def main():
     kernel_time = {k: G.timer(k) for k in ("apply_u_matrix_free", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr",
                                            "halo_exchange", "allreduce")}
 
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    # tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py); null when no profile is committed
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_kron_v3.json")) as f:
+            traffic = json.load(f)["poro::k_kron3_q2"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "DoF-updates/sec in assemble+SpMV per fixed-stress iter", "value": updates / elapsed, "unit": "DoF-updates/s",
@@ -176,8 +185,8 @@ def main():
                                    f"(pressure loop + matrix-free Jacobi-PCG displacement solve + strain projection); input.data material/BCs, z-face BCs per SURVEY Q9",
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU", "operator": "matrix_free",
                        "stopping_rule_u": f"recursive residual <= max(1e-12, {args.rel_tol:g}*||b||), cap {args.max_iter}"},
-            "roofline": {"bound": "hbm", "kernel": "k_mf_apply (matrix-free y = A_u x)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_kron3_q2 (matrix-free y = A_u x, sum-factorised)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e6 * avg_apply, "launches_timed": n_apply},
             "work_per_step": {k: work[k] / args.steps for k in work},
             "kernel_only": {"apply_u_DoF_updates_per_s": (P.desc.n_dofs_u / avg_apply) if n_apply else 0.0,

@@ -36,7 +36,7 @@ constexpr int kScalarSlots = 32;
 // device-resident scalars of a PCG solve (no host round trip inside the iteration)
 struct PcgScalars {
   double dh, gg, gz;         // reductions of the current iteration (after all-reduce)
-  double gh;                 // g.z of the previous iteration
+  double gh2[2];             // g.z of the previous iteration (ping-pong by iteration parity in the fused path; [0] otherwise)
   double alpha, beta;
   double tol, res0, res;
   int32_t it, done, converged, max_iter;
@@ -135,6 +135,11 @@ void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *
 void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red /*bb, gg, gz*/, double abs_tol, double rel_tol, int max_iter);
 void pcg_scalars_alpha(hipStream_t s, PcgScalars *sc, const double *red /*dh*/);
 void pcg_scalars_beta(hipStream_t s, PcgScalars *sc, const double *red /*gg, gz*/);
+// single-rank fast path: the consumers reduce the block partials themselves (no scalar kernels, no host round trip);
+// parity = iteration index & 1 selects the g.z slot read / written
+void pcg_update_xg_fused(hipStream_t s, PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec,
+                         int64_t n, const double *partials_dh, double *partials_out /*2 sets*/);
+void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in /*2 sets*/);
 
 // ---- kernels_asm.hip ----------------------------------------------------------------------------
 struct AsmArgs {
@@ -160,6 +165,7 @@ void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
 
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);
-void kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus);
+// dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
+void kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr);
 
 }  // namespace poro

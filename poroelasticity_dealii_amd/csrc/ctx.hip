@@ -200,46 +200,65 @@ double *vec(poro_ctx *c, int which) {
 int64_t vec_len(poro_ctx *c, int which) { return (int64_t)c->vec.at(which).n; }
 bool is_u_vec(int which) { return which == PORO_VEC_U || which == PORO_VEC_RHS_U || which == PORO_VEC_DIAG_U; }
 
-void apply_A_u(poro_ctx *c, const double *x, double *y, int mode) {
+// y = A_u x (+ interface exchange).  dot_partials != null asks for the block partials of x.y; returns true when they were produced
+// by the operator kernel itself (fused), false when the caller still has to launch the dot kernel.
+bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr) {
+  bool fused = false;
   {
     Timed tm(c, mode == PORO_OP_MATRIX_FREE ? "apply_u_matrix_free" : "apply_u_csr");
-    if (mode == PORO_OP_MATRIX_FREE) mf_operator(c, x, y, true);
-    else la_csr_spmv(c->stream, c->Au, c->Au_val.p, x, y);
+    if (mode == PORO_OP_MATRIX_FREE) {
+      if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) { kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials); fused = dot_partials != nullptr; }
+      else mf_apply(c->stream, mf_args(c), x, y, true);
+    } else la_csr_spmv(c->stream, c->Au, c->Au_val.p, x, y);
   }
   exchange_add(c, y, c->n_u, c->comm.part.plane_u);
+  return fused;
 }
 
 // ---- PCG with device-side control: SolverCG<>::solve restated, Jacobi instead of SSOR ---------------
-int pcg(poro_ctx *c, const std::function<void(const double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
+// apply(x, y, dot_partials) as apply_A_u.  Single rank: the vector kernels reduce the block partials in their prologues (3 launches
+// per iteration incl. the operator); partitioned: explicit sums + all-reduces between the kernels.
+int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
         const double *diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
   hipStream_t s = c->stream;
   const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
   const int64_t n_own = owned(c, n, plane);
+  const bool multi = c->comm.multi();
   double *part = c->partials.p, *red = c->red.p; PcgScalars *sc = c->scal.p;
+  double *part_dh = part + 3 * (size_t)kMaxPartials;      // slots of the fused / separate d.h partials
   hipEvent_t e0, e1; PORO_HIP(hipEventCreate(&e0)); PORO_HIP(hipEventCreate(&e1)); PORO_HIP(hipEventRecord(e0, s));
   int64_t applies = 0;
   // g = A x - b ; d = -P^-1 g ; gh = g.P^-1 g
-  apply(x, h); ++applies;
+  apply(x, h, nullptr); ++applies;
   pcg_init_residual(s, g, h, b, n);
   la_dot_partials(s, b, b, n_own, part);
   pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
   pcg_scalars_sum(s, part, 3, red);
   allreduce_sum(c, red, 3);
   pcg_scalars_start(s, sc, red, opts->abs_tol, opts->rel_tol, opts->max_iter);
+  PORO_HIP(hipMemsetAsync(part_dh, 0, kMaxPartials * sizeof(double), s));
   PcgScalars hs{};
-  int batch = 4;
+  int batch = 4, it = 0;
   while (true) {
     PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
     if (hs.done) break;
     for (int k = 0; k < batch; ++k) {
-      apply(d, h); ++applies;
-      pcg_dot_dh(s, sc, d, h, n_own, part);
-      pcg_scalars_sum(s, part, 1, red); allreduce_sum(c, red, 1);
-      pcg_scalars_alpha(s, sc, red);
-      pcg_update_xg(s, sc, x, g, d, h, diag, prec, n, n_own, part);
-      pcg_scalars_sum(s, part, 2, red); allreduce_sum(c, red, 2);
-      pcg_scalars_beta(s, sc, red);
-      pcg_update_d(s, sc, d, g, diag, prec, n);
+      ++it;
+      if (!multi) {
+        if (!apply(d, h, part_dh)) pcg_dot_dh(s, sc, d, h, n, part_dh);
+        ++applies;
+        pcg_update_xg_fused(s, sc, (it - 1) & 1, x, g, d, h, diag, prec, n, part_dh, part);
+        pcg_update_d_fused(s, sc, (it - 1) & 1, it, d, g, diag, prec, n, part);
+      } else {
+        apply(d, h, nullptr); ++applies;
+        pcg_dot_dh(s, sc, d, h, n_own, part);
+        pcg_scalars_sum(s, part, 1, red); allreduce_sum(c, red, 1);
+        pcg_scalars_alpha(s, sc, red);
+        pcg_update_xg(s, sc, x, g, d, h, diag, prec, n, n_own, part);
+        pcg_scalars_sum(s, part, 2, red); allreduce_sum(c, red, 2);
+        pcg_scalars_beta(s, sc, red);
+        pcg_update_d(s, sc, d, g, diag, prec, n);
+      }
     }
     if (batch < 32) batch *= 2;
   }
@@ -484,7 +503,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     PORO_HIP(hipSetDevice(c->device));
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
-    auto apply = [&](const double *x, double *y) { apply_A_u(c, x, y, mode); };
+    auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp); };
     const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->diag_u.p, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
     la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);   // constraints.distribute (:306)
     PORO_HIP(hipStreamSynchronize(c->stream));
@@ -527,7 +546,7 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (c->jac_dt < 0) throw Error("pres_solve before pres_assemble_jacobian");
-    auto apply = [&](const double *x, double *y) { { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); } exchange_add(c, y, c->n_p, c->comm.part.plane_p); };
+    auto apply = [&](const double *x, double *y, double *) { { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); } exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false; };
     return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->diag_J.p, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
   });
 }
@@ -572,7 +591,7 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
     PORO_HIP(hipSetDevice(c->device));
     if (!c->projection_matrix_ready) throw Error("proj_solve before proj_assemble_matrix");
     if (entry < 0 || entry >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
-    auto apply = [&](const double *x, double *y) { { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); } exchange_add(c, y, c->n_p, c->comm.part.plane_p); };
+    auto apply = [&](const double *x, double *y, double *) { { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); } exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false; };
     return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->diag_M.p, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
   });
 }

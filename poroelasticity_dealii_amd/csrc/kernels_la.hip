@@ -206,13 +206,13 @@ __global__ void k_scalars_start(PcgScalars *sc, const double *red, double abs_to
   const double bb = red[0], gg = red[1], gz = red[2];
   sc->tol = fmax(abs_tol, rel_tol * sqrt(bb));
   sc->res0 = sc->res = sqrt(gg);
-  sc->gg = gg; sc->gz = gz; sc->gh = gz; sc->dh = 0; sc->alpha = 0; sc->beta = 0;
+  sc->gg = gg; sc->gz = gz; sc->gh2[0] = gz; sc->gh2[1] = gz; sc->dh = 0; sc->alpha = 0; sc->beta = 0;
   sc->it = 0; sc->max_iter = max_iter;
   sc->converged = sc->res <= sc->tol; sc->done = sc->converged;
 }
 __global__ void k_scalars_alpha(PcgScalars *sc, const double *red) {
   if (sc->done) return;
-  sc->dh = red[0]; sc->alpha = sc->gh / red[0];
+  sc->dh = red[0]; sc->alpha = sc->gh2[0] / red[0];
 }
 __global__ void k_scalars_beta(PcgScalars *sc, const double *red) {
   if (sc->done) return;
@@ -220,7 +220,55 @@ __global__ void k_scalars_beta(PcgScalars *sc, const double *red) {
   sc->it += 1; sc->gg = gg; sc->gz = gz; sc->res = sqrt(gg);
   if (sc->res <= sc->tol) { sc->done = 1; sc->converged = 1; return; }        // SolverControl::success
   if (sc->it >= sc->max_iter) { sc->done = 1; sc->converged = 0; return; }    // SolverControl::failure -> NoConvergence
-  sc->beta = gz / sc->gh; sc->gh = gz;
+  sc->beta = gz / sc->gh2[0]; sc->gh2[0] = gz;
+}
+
+// sum of kMaxPartials block partials in a fixed order, broadcast to every thread of the block (identical bits in every block)
+__device__ inline double sum_partials(const double *p, double *sh /*[5]*/) {
+  double v = 0;
+  for (int i = threadIdx.x; i < kMaxPartials; i += kBlock) v += p[i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) sh[4] = v;
+  __syncthreads();
+  v = sh[4];
+  __syncthreads();
+  return v;
+}
+__global__ void k_pcg_update_xg_fused(PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
+                                      const double *partials_dh, double *partials_out) {
+  __shared__ double sh[5];
+  if (sc->done) return;
+  const double dh = sum_partials(partials_dh, sh);
+  const double alpha = sc->gh2[parity] / dh;
+  double gg = 0, gz = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double gi = g[i] + alpha * h[i];
+    g[i] = gi; x[i] += alpha * d[i];
+    const double z = prec ? gi / diag[i] : gi; gg += gi * gi; gz += gi * z;
+  }
+  gg = block_sum(gg, sh); gz = block_sum(gz, sh);
+  store_partial(partials_out, gg); store_partial(partials_out + kMaxPartials, gz);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
+}
+// `it` = 1-based index of this iteration, supplied by the host (launch order), so no block depends on a control word that
+// another block of the same launch updates; only block 0 writes the control words
+__global__ void k_pcg_update_d_fused(PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in) {
+  __shared__ double sh[5];
+  if (sc->done) return;
+  const double gg = sum_partials(partials_in, sh), gz = sum_partials(partials_in + kMaxPartials, sh);
+  const double res = sqrt(gg), gh_old = sc->gh2[parity];
+  const bool conv = res <= sc->tol, fail = !conv && it >= sc->max_iter;      // SolverControl::check order: success first, then the cap
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gg = gg; sc->gz = gz; sc->res = res; sc->it = it; }
+  if (conv || fail) {   // every block takes this branch together (identical inputs); a block that starts late sees done = 1 and returns above
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->converged = conv ? 1 : 0; __threadfence(); sc->done = 1; }
+    return;
+  }
+  const double beta = gz / gh_old;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double gi = g[i], z = prec ? gi / diag[i] : gi;
+    d[i] = beta * d[i] - z;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->gh2[parity ^ 1] = gz; }
 }
 
 template <class F> void dispatch_lanes(int L, F &&f) {
@@ -306,6 +354,13 @@ void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *
 }
 void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red, double abs_tol, double rel_tol, int max_iter) {
   hipLaunchKernelGGL(k_scalars_start, 1, 1, 0, s, sc, red, abs_tol, rel_tol, max_iter);
+}
+void pcg_update_xg_fused(hipStream_t s, PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
+                         const double *partials_dh, double *partials_out) {
+  hipLaunchKernelGGL(k_pcg_update_xg_fused, reduce_grid(n), kBlock, 0, s, sc, parity, x, g, d, h, diag, prec, n, partials_dh, partials_out);
+}
+void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in) {
+  hipLaunchKernelGGL(k_pcg_update_d_fused, reduce_grid(n), kBlock, 0, s, sc, parity, it, d, g, diag, prec, n, partials_in);
 }
 void pcg_scalars_alpha(hipStream_t s, PcgScalars *sc, const double *red) { hipLaunchKernelGGL(k_scalars_alpha, 1, 1, 0, s, sc, red); }
 void pcg_scalars_beta(hipStream_t s, PcgScalars *sc, const double *red) { hipLaunchKernelGGL(k_scalars_beta, 1, 1, 0, s, sc, red); }
