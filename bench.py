@@ -171,7 +171,7 @@ def main():
     # tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py); null when no profile is committed
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_kron_v3.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_kron_v2.json")) as f:
             traffic = json.load(f)["poro::k_kron3_q2"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass

@@ -44,6 +44,7 @@ struct KronArgs {
   int nn[3]; int ntx, nty, nzc, chunk;   // chunk = planes per z-chunk (even)
   KronConsts k;
   const uint8_t *nodemask; int constrained, mask_anywhere;
+  double *dot_partials;   // optional: per-workgroup partial of x.y over the free rows (x is zero on the Dirichlet columns after masking)
 };
 
 __device__ inline int64_t xcd_remap(int64_t bid, int64_t n) {
@@ -114,6 +115,7 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
 
   // one plane: z-stage in registers -> LDS (double buffered: ONE barrier per plane) -> y-stage -> x-stage -> store
   int buf = 0;
+  double dot_acc = 0.0;
   auto plane = [&](const int kk, const bool oddz, auto &&after_zstage) {
     double *Lw = L + buf * (9 * TYR * TXN);
     {
@@ -195,6 +197,8 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
     if (out) {   // constrained rows are rewritten by k_kron_fix_constrained afterwards
       const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
       y[d0] = yv[0]; y[d0 + 1] = yv[1]; y[d0 + 2] = yv[2];
+      const double (&xc)[3] = oddz ? W3 : W2;          // this plane's (masked) input values
+      dot_acc = fma(xc[0], yv[0], fma(xc[1], yv[1], fma(xc[2], yv[2], dot_acc)));
     }
   };
 
@@ -206,12 +210,32 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
     for (int c = 0; c < 3; ++c) { const double t0 = W0[c], t1 = W1[c]; W0[c] = W2[c]; W1[c] = W3[c]; W2[c] = W4[c]; W3[c] = t0; W4[c] = t1; }
     apply_mask(W3, m0); apply_mask(W4, m1);
   }
+  if (a.dot_partials) {   // deterministic workgroup reduction of x.y (fixed shuffle tree, waves summed in index order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_xor(dot_acc, off, 64);
+    __syncthreads();
+    if (lane == 0) L[w] = dot_acc;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int q = 0; q < TYR; ++q) t += L[q]; a.dot_partials[blockIdx.x] = t; }
+  }
 }
 
 // y_i = diag_i x_i on the Dirichlet rows (ConstraintMatrix elimination), from the constraint list
-__global__ void k_kron_fix_constrained(int64_t n, const int32_t *__restrict__ dofs, const double *__restrict__ diag_local, const double *__restrict__ x, double *__restrict__ y) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) { const int32_t d = dofs[t]; y[d] = diag_local[d] * x[d]; }
+__global__ void __launch_bounds__(256)
+k_kron_fix_constrained(int64_t n, const int32_t *__restrict__ dofs, const double *__restrict__ diag_local, const double *__restrict__ x, double *__restrict__ y,
+                       double *dot_partials /* optional: slot per block for sum x_i y_i over the Dirichlet rows */) {
+  __shared__ double sh[4];
+  double acc = 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t d = dofs[t]; const double xv = x[d], yv = diag_local[d] * xv; y[d] = yv; acc = fma(xv, yv, acc);
+  }
+  if (dot_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dot_partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  }
 }
 
 // checks the integer element matrices above against Gauss quadrature of the Lagrange basis (4 points on [0,1], exact to degree 7)
@@ -234,7 +258,7 @@ void check_q2_element_matrices() {
 
 bool kron_supported(int dim, int k_u) { return dim == 3 && k_u == 2; }
 
-void kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus) {
+void kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials) {
   static bool checked = false;
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
@@ -255,8 +279,13 @@ void kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool
   const size_t lds = (size_t)NFLD * TYR * TXN * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) { PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-  hipLaunchKernelGGL(k_kron3_q2, (unsigned)(a.ntx * a.nty * a.nzc), 1024, lds, s, a, x, y);
-  if (constrained && m.n_dirichlet) hipLaunchKernelGGL(k_kron_fix_constrained, (unsigned)((m.n_dirichlet + 255) / 256), 256, 0, s, m.n_dirichlet, m.dirichlet_dofs, m.diag_local, x, y);
+  const int nblk = a.ntx * a.nty * a.nzc;
+  // one Dirichlet dof per thread when the partial slots allow it (the list kernel is latency-bound)
+  const int nfix = (constrained && m.n_dirichlet) ? (int)std::min<int64_t>((m.n_dirichlet + 255) / 256, dot_partials ? std::max(1, kMaxPartials - nblk) : 4096) : 0;
+  if (dot_partials && nblk + nfix > kMaxPartials) throw Error("kron_apply: too many workgroups for the fused dot product");
+  a.dot_partials = dot_partials;
+  hipLaunchKernelGGL(k_kron3_q2, (unsigned)nblk, 1024, lds, s, a, x, y);
+  if (nfix) hipLaunchKernelGGL(k_kron_fix_constrained, (unsigned)nfix, 256, 0, s, m.n_dirichlet, m.dirichlet_dofs, m.diag_local, x, y, dot_partials ? dot_partials + nblk : (double *)nullptr);
 }
 
 }  // namespace poro
