@@ -464,7 +464,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
         mf_diag(s, mf_args(c), c->diag_u_local.p);
         // lifting: -(A_full g) on the free rows, through the unconstrained operator
         mf_operator(c, c->dir_val.p, c->wh_u.p, false);
-        if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
+        if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u) && !std::getenv("PORO_DIAG_SKIP_SELFCHECK")) {
           // self-check of the sum-factorised operator against the element-matrix gather on a synthetic vector (guards the
           // FE-table / numbering assumptions of the structured path); both unconstrained
           std::vector<double> hx(c->n_u); for (int64_t i = 0; i < c->n_u; ++i) hx[i] = std::sin(0.37 * (double)i);

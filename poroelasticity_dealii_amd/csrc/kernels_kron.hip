@@ -52,6 +52,19 @@ __device__ inline int64_t xcd_remap(int64_t bid, int64_t n) {
   return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 
+// whole-wave lane shifts by DPP (VALU, no LDS round trip): lane l receives the value of lane l-1 (up) / l+1 (down); the lanes at the
+// wave edge receive 0 (bound_ctrl) - they are tile-halo lanes whose results are never stored
+__device__ inline double wave_up1(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_dn1(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ void __launch_bounds__(1024)
 k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];                            // [NFLD][TYR][TXN]
@@ -147,7 +160,9 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
     double wz[3];
     if (has_w) { const double cD = 3.0 * ((kk > 0 ? 1.0 : 0.0) - (kk < NZ - 1 ? 1.0 : 0.0)); wz[0] = cD * W2[0]; wz[1] = cD * W2[1]; wz[2] = cD * W2[2]; }
     after_zstage();                                    // (the even plane issues the prefetch of the next pair here: W0, W1 are dead now)
+#ifndef PORO_DIAG_NO_BARRIER
     __syncthreads();
+#endif
     Lb = Lw; buf ^= 1;
 
     double XK[3], XM[3], XO[3], XD[3];
@@ -190,8 +205,12 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
       const double t2 = pe * (FK - FM);                  // +-2 coupling exists only between vertex nodes
       const double pO = pe * FO;
       double s = fma(cKx, FK, fma(cMx, FM, cDx * FD));
-      s += __shfl_up(fma(4.0, FO, t1), 1) + __shfl_down(fma(-4.0, FO, t1), 1);     // from i-1 (its +1 message) and i+1 (its -1 message)
-      s += __shfl_up(t2 - pO, 2) + __shfl_down(t2 + pO, 2);                        // from i-2 and i+2
+#ifndef PORO_DIAG_NO_SHUFFLE
+      s += wave_up1(fma(4.0, FO, t1)) + wave_dn1(fma(-4.0, FO, t1));               // from i-1 (its +1 message) and i+1 (its -1 message)
+      s += wave_up1(wave_up1(t2 - pO)) + wave_dn1(wave_dn1(t2 + pO));              // from i-2 and i+2
+#else
+      s += fma(4.0, FO, t1) + fma(-4.0, FO, t1) + (t2 - pO) + (t2 + pO);
+#endif
       yv[c] = s;
     }
     if (out) {   // constrained rows are rewritten by k_kron_fix_constrained afterwards
