@@ -22,10 +22,10 @@
 namespace poro {
 namespace {
 
-constexpr int TXN = 64;          // nodes per row of the tile = lanes of a wave (60 valid)
-constexpr int TYR = 16;          // rows of the tile = waves of the workgroup (12 valid)
+// Two tile shapes share the kernel body: 64 lanes x 16 rows (one row per wave, 60 x 12 valid outputs) and, for the remainder of
+// the x-extent, 32 lanes x 32 rows (two rows of equal parity per wave, 28 x 28 valid).  Both hold 1024 nodes per plane.
 constexpr int NFLD = 18;         // two buffers of the 9 z-stage fields of a plane
-constexpr int VX = 60, VY = 12;  // valid outputs per tile
+constexpr int kTileNodes = 1024;
 
 // FE_Q(2) 1D element matrices on a cell of length h are small-integer matrices times a scale:
 //   M = (h/30) [[4,2,-1],[2,16,2],[-1,2,4]],  K = (1/3h) [[7,-8,1],[-8,16,-8],[1,-8,7]],  C = (1/6) [[-3,-4,1],[4,0,-4],[-1,4,3]]
@@ -41,7 +41,7 @@ struct KronConsts {
   double cc_mx[4];                             // c1..c4 * sC sMx sC   (O_y / D_y of oz / wz  -> XM)
 };
 struct KronArgs {
-  int nn[3]; int ntx, nty, nzc, chunk;   // chunk = planes per z-chunk (even)
+  int nn[3]; int n64, nty64, has32, nty32, x0_32, nzc, chunk, nA, nblocks;   // chunk = planes per z-chunk (even); nA = workgroups with 64-lane tiles
   KronConsts k;
   const uint8_t *nodemask; int constrained, mask_anywhere;
   double *dot_partials;   // optional: per-workgroup partial of x.y over the free rows (x is zero on the Dirichlet columns after masking)
@@ -65,25 +65,29 @@ __device__ inline double wave_dn1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(1024)
-k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
-  extern __shared__ double L[];                            // [NFLD][TYR][TXN]
+// rows of the tile handled by wave w (both of one parity); waves w, w+4, w+8, w+12 share a SIMD, so the tables give every SIMD
+// a similar mix of vertex rows (5-point y-band), mid rows (3-point) and halo rows (z-stage only)
+__device__ const signed char kRows64[16] = {2, 4, 6, 8, 3, 5, 7, 9, 10, 11, 12, 13, 1, 0, 15, 14};
+__device__ const signed char kRows32a[16] = {2, 6, 10, 14, 3, 7, 11, 15, 18, 22, 26, 27, 19, 23, 0, 1};
+__device__ const signed char kRows32b[16] = {4, 8, 12, 16, 5, 9, 13, 17, 20, 24, 28, 29, 21, 25, 30, 31};
+
+template <int TXN>
+__device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__restrict__ x, double *__restrict__ y, double *L, const int X0, const int tyi, const int zc) {
+  constexpr int RPW = 64 / TXN, TYR = 16 * RPW, VY = TYR - 4;   // rows per wave, rows per tile, valid rows
+  static_assert(TXN * TYR == kTileNodes, "tile");
   const int tid = threadIdx.x;
   const int NX = a.nn[0], NY = a.nn[1], NZ = a.nn[2];
-  const int64_t nblocks = (int64_t)a.ntx * a.nty * a.nzc;
-  const int64_t tile = xcd_remap(blockIdx.x, nblocks);
-  const int zc = (int)(tile % a.nzc), tyi = (int)((tile / a.nzc) % a.nty), txi = (int)(tile / ((int64_t)a.nzc * a.nty));
-  const int X0 = VX * txi - 2, Y0 = VY * tyi - 2;
+  const int Y0 = VY * tyi - 2;
   const int k0 = zc * a.chunk, k1 = min(NZ, k0 + a.chunk);
 
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  // waves w, w+4, w+8, w+12 share a SIMD: give each SIMD 1-2 vertex rows, 1-2 mid rows and one halo row
-  const int r = (w < 4) ? 2 + 2 * w : (w < 8) ? 3 + 2 * (w - 4) : (w < 12) ? w + 2 : (w == 12 ? 1 : w == 13 ? 0 : w == 14 ? 15 : 14);
-  const bool odd_row = (r & 1) != 0, halo_wave = r < 2 || r > 13;
-  const int j = Y0 + r, i = X0 + lane;
-  const bool even_i = (lane & 1) == 0;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lx = lane % TXN;
+  const int ra = RPW == 1 ? kRows64[w] : kRows32a[w], rb = RPW == 1 ? ra : kRows32b[w];
+  const int r = (RPW == 2 && lane >= TXN) ? rb : ra;
+  const bool odd_row = (ra & 1) != 0, halo_wave = ra < 2 || ra > TYR - 3;
+  const int j = Y0 + r, i = X0 + lx;
+  const bool even_i = (lx & 1) == 0;
   const bool vj = j >= 0 && j < NY, vn = vj && i >= 0 && i < NX;
-  const bool out = vn && lane >= 2 && lane <= 61 && !halo_wave;
+  const bool out = vn && lx >= 2 && lx <= TXN - 3 && !halo_wave;
   const bool bnd_xy = i == 0 || i == NX - 1 || j == 0 || j == NY - 1;
 
   // centre coefficients (the only place the domain boundary enters); pe switches the +-2 messages off for mid nodes
@@ -108,15 +112,15 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   };
 
   double W0[3], W1[3], W2[3], W3[3], W4[3];
-  unsigned m0, m1, m2, m3, m4;
-  load_plane(k0 - 2, W0, m0); load_plane(k0 - 1, W1, m1); load_plane(k0, W2, m2); load_plane(k0 + 1, W3, m3); load_plane(k0 + 2, W4, m4);
-  apply_mask(W0, m0); apply_mask(W1, m1); apply_mask(W2, m2); apply_mask(W3, m3); apply_mask(W4, m4);
+  unsigned m0, m1;
+  load_plane(k0 - 2, W0, m0); apply_mask(W0, m0); load_plane(k0 - 1, W1, m0); apply_mask(W1, m0); load_plane(k0, W2, m0); apply_mask(W2, m0);
+  load_plane(k0 + 1, W3, m0); apply_mask(W3, m0); load_plane(k0 + 2, W4, m0); apply_mask(W4, m0);
 
   // y-stage helpers: neighbours and the node's own value of field q come from the LDS buffer `Lb`
   const double *Lb = L;
   double s1, s2, d1, d2, own;   // v(-1)+v(+1), v(-2)+v(+2), v(-1)-v(+1), v(+2)-v(-2), v(0)
   auto nb = [&](int q) {
-    const double *col = Lb + (q * TYR + r) * TXN + lane;
+    const double *col = Lb + (q * TYR + r) * TXN + lx;
     const double nm1 = col[-TXN], np1 = col[TXN];
     own = col[0];
     s1 = nm1 + np1; d1 = nm1 - np1;
@@ -154,25 +158,66 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
       }
       // safe without a barrier: every wave passed the previous barrier only after it finished reading this buffer two planes ago
 #pragma unroll
-      for (int q = 0; q < 9; ++q) Lw[(q * TYR + r) * TXN + lane] = f[q];
+      for (int q = 0; q < 9; ++q) Lw[(q * TYR + r) * TXN + lx] = f[q];
     }
-    const bool has_w = !oddz && (kk == 0 || kk == NZ - 1);   // workgroup-uniform
-    double wz[3];
-    if (has_w) { const double cD = 3.0 * ((kk > 0 ? 1.0 : 0.0) - (kk < NZ - 1 ? 1.0 : 0.0)); wz[0] = cD * W2[0]; wz[1] = cD * W2[1]; wz[2] = cD * W2[2]; }
     after_zstage();                                    // (the even plane issues the prefetch of the next pair here: W0, W1 are dead now)
 #ifndef PORO_DIAG_NO_BARRIER
     __syncthreads();
 #endif
     Lb = Lw; buf ^= 1;
 
+    const bool has_w = !oddz && (kk == 0 || kk == NZ - 1);   // workgroup-uniform: first / last plane of the box
+    // x-stage of one component, scatter form: the node's own term + messages to the nodes at +-1 and (vertex nodes only) +-2
+    auto xstage = [&](const double FK, const double FM, const double FO, const double FD) {
+      const double t1 = fma(-8.0, FK, 2.0 * FM);         // K / M part of the +-1 coupling (the same for vertex and mid sources)
+      const double t2 = pe * (FK - FM);                  // +-2 coupling exists only between vertex nodes
+      const double pO = pe * FO;
+      double sacc = fma(cKx, FK, fma(cMx, FM, cDx * FD));
+#ifndef PORO_DIAG_NO_SHUFFLE
+      sacc += wave_up1(fma(4.0, FO, t1)) + wave_dn1(fma(-4.0, FO, t1));               // from i-1 (its +1 message) and i+1 (its -1 message)
+      sacc += wave_up1(wave_up1(t2 - pO)) + wave_dn1(wave_dn1(t2 + pO));              // from i-2 and i+2
+#else
+      sacc += fma(4.0, FO, t1) + fma(-4.0, FO, t1) + (t2 - pO) + (t2 + pO);
+#endif
+      return sacc;
+    };
+    const double (&xc)[3] = oddz ? W3 : W2;            // this plane's (masked) input values, for the fused x.y
+    const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
+    auto emit = [&](int c, double v) { if (out) { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); } };   // constrained rows are rewritten by k_kron_fix_constrained
+
+    if (!has_w) {
+      if (halo_wave) return;
+      // field order chosen so that the inputs of component x, then y, then z complete early and their registers die
+      double XK0, XM0, XO0, XD0, XK1, XM1, XO1, XD1;
+      { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_x
+        XK0 = K.xk_l2g * My; XM0 = K.m_gKyMz * Ky; XO1 = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD1 = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
+      { nb(3); XM0 = fma(K.m_gMyKz, sweepM(), XM0); }                                      // kz_x
+      { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_y
+        XK1 = K.xk_g * My; XM1 = K.m_lKyMz * Ky; XO0 = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD0 = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
+      { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                  // oz_z
+        XO0 = fma(K.cc_oz[0], My, XO0); XD0 = fma(K.cc_oz[2], My, XD0); XM1 = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM1)); }
+      emit(0, xstage(XK0, XM0, XO0, XD0));
+      { nb(4); XM1 = fma(K.m_gMyKz, sweepM(), XM1); }                                      // kz_y
+      emit(1, xstage(XK1, XM1, XO1, XD1));
+      double XK2, XM2, XO2, XD2;
+      { nb(2); const double My = sweepM(), Ky = sweepK(); XK2 = K.xk_g * My; XM2 = K.m_gKyMz * Ky; }   // mz_z
+      { nb(5); XM2 = fma(K.m_lMyKz, sweepM(), XM2); }                                      // kz_z
+      { nb(6); const double My = sweepM(); XO2 = K.cc_oz[0] * My; XD2 = K.cc_oz[1] * My; } // oz_x
+      { nb(7); const double Oy = sweepO(), Dy = cDy * own; XM2 = fma(K.cc_mx[0], Oy, fma(K.cc_mx[1], Dy, XM2)); }   // oz_y
+      emit(2, xstage(XK2, XM2, XO2, XD2));
+      return;
+    }
+
+    // first / last plane of the box (two planes per box): additionally the boundary diagonal D_z of C_z, wz = cD u, which goes
+    // through slots 0..2 of the same buffer in a second round
     double XK[3], XM[3], XO[3], XD[3];
+    const double cD = 3.0 * ((kk > 0 ? 1.0 : 0.0) - (kk < NZ - 1 ? 1.0 : 0.0));
     if (!halo_wave) {
       { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_x
         XK[0] = K.xk_l2g * My; XM[0] = K.m_gKyMz * Ky; XO[1] = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD[1] = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
       { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_y
         XK[1] = K.xk_g * My; XM[1] = K.m_lKyMz * Ky; XO[0] = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD[0] = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
-      { nb(2); const double My = sweepM(), Ky = sweepK();                                    // mz_z
-        XK[2] = K.xk_g * My; XM[2] = K.m_gKyMz * Ky; }
+      { nb(2); const double My = sweepM(), Ky = sweepK(); XK[2] = K.xk_g * My; XM[2] = K.m_gKyMz * Ky; }   // mz_z
       { nb(3); XM[0] = fma(K.m_gMyKz, sweepM(), XM[0]); }                                    // kz_x
       { nb(4); XM[1] = fma(K.m_gMyKz, sweepM(), XM[1]); }                                    // kz_y
       { nb(5); XM[2] = fma(K.m_lMyKz, sweepM(), XM[2]); }                                    // kz_z
@@ -181,44 +226,20 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
       { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                    // oz_z
         XO[0] = fma(K.cc_oz[0], My, XO[0]); XD[0] = fma(K.cc_oz[2], My, XD[0]); XM[1] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM[1])); }
     }
-    if (has_w) {   // first / last plane of the box: the boundary diagonal D_z of C_z, wz = cD u, through slots 0..2 of the same buffer
-      __syncthreads();
+    __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Lw[(c * TYR + r) * TXN + lane] = wz[c];
-      __syncthreads();
-      if (!halo_wave) {
-        { nb(0); const double My = sweepM(); XO[2] = fma(K.cc_oz[2], My, XO[2]); XD[2] = fma(K.cc_oz[3], My, XD[2]); }            // wz_x
-        { nb(1); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[2], Oy, fma(K.cc_mx[3], Dy, XM[2])); }           // wz_y
-        { nb(2); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                                                       // wz_z
-          XO[0] = fma(K.cc_oz[1], My, XO[0]); XD[0] = fma(K.cc_oz[3], My, XD[0]); XM[1] = fma(K.cc_mx[1], Oy, fma(K.cc_mx[3], Dy, XM[1])); }
-      }
-      __syncthreads();   // slots 0..2 must not be overwritten by a fast wave's plane kk+2 before everybody has read wz (same buffer)
+    for (int c = 0; c < 3; ++c) Lw[(c * TYR + r) * TXN + lx] = cD * xc[c];
+    __syncthreads();
+    if (!halo_wave) {
+      { nb(0); const double My = sweepM(); XO[2] = fma(K.cc_oz[2], My, XO[2]); XD[2] = fma(K.cc_oz[3], My, XD[2]); }            // wz_x
+      { nb(1); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[2], Oy, fma(K.cc_mx[3], Dy, XM[2])); }           // wz_y
+      { nb(2); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                                                       // wz_z
+        XO[0] = fma(K.cc_oz[1], My, XO[0]); XD[0] = fma(K.cc_oz[3], My, XD[0]); XM[1] = fma(K.cc_mx[1], Oy, fma(K.cc_mx[3], Dy, XM[1])); }
     }
+    __syncthreads();   // slots 0..2 must not be overwritten by a fast wave's plane kk+2 before everybody has read wz (same buffer)
     if (halo_wave) return;
-
-    // ---- x-stage, scatter form: the node's own term + messages to the nodes at +-1 and (vertex nodes only) +-2 ----
-    double yv[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double FK = XK[c], FM = XM[c], FO = XO[c], FD = XD[c];
-      const double t1 = fma(-8.0, FK, 2.0 * FM);         // K / M part of the +-1 coupling (the same for vertex and mid sources)
-      const double t2 = pe * (FK - FM);                  // +-2 coupling exists only between vertex nodes
-      const double pO = pe * FO;
-      double s = fma(cKx, FK, fma(cMx, FM, cDx * FD));
-#ifndef PORO_DIAG_NO_SHUFFLE
-      s += wave_up1(fma(4.0, FO, t1)) + wave_dn1(fma(-4.0, FO, t1));               // from i-1 (its +1 message) and i+1 (its -1 message)
-      s += wave_up1(wave_up1(t2 - pO)) + wave_dn1(wave_dn1(t2 + pO));              // from i-2 and i+2
-#else
-      s += fma(4.0, FO, t1) + fma(-4.0, FO, t1) + (t2 - pO) + (t2 + pO);
-#endif
-      yv[c] = s;
-    }
-    if (out) {   // constrained rows are rewritten by k_kron_fix_constrained afterwards
-      const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
-      y[d0] = yv[0]; y[d0 + 1] = yv[1]; y[d0 + 2] = yv[2];
-      const double (&xc)[3] = oddz ? W3 : W2;          // this plane's (masked) input values
-      dot_acc = fma(xc[0], yv[0], fma(xc[1], yv[1], fma(xc[2], yv[2], dot_acc)));
-    }
+    for (int c = 0; c < 3; ++c) emit(c, xstage(XK[c], XM[c], XO[c], XD[c]));
   };
 
   for (int k = k0; k < k1; k += 2) {
@@ -235,8 +256,16 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
     __syncthreads();
     if (lane == 0) L[w] = dot_acc;
     __syncthreads();
-    if (tid == 0) { double t = 0; for (int q = 0; q < TYR; ++q) t += L[q]; a.dot_partials[blockIdx.x] = t; }
+    if (tid == 0) { double t = 0; for (int q = 0; q < 16; ++q) t += L[q]; a.dot_partials[blockIdx.x] = t; }
   }
+}
+
+__global__ void __launch_bounds__(1024)
+k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ double L[];                            // [2 buffers][9 fields][1024 nodes of the tile plane]
+  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);  // workgroup-uniform: either tile shape, never both
+  if (tile < a.nA) kron_tile<64>(a, x, y, L, 60 * (tile / (a.nzc * a.nty64)) - 2, (tile / a.nzc) % a.nty64, tile % a.nzc);
+  else { const int t = tile - a.nA; kron_tile<32>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
 }
 
 // y_i = diag_i x_i on the Dirichlet rows (ConstraintMatrix elimination), from the constraint list
@@ -282,12 +311,19 @@ void kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
   for (int d = 0; d < 3; ++d) a.nn[d] = 2 * m.box.n[d] + 1;
-  a.ntx = (a.nn[0] + VX - 1) / VX; a.nty = (a.nn[1] + VY - 1) / VY;
+  // x-extent = full 60-wide tiles + (when what is left fits) one 28-wide tile column
+  a.n64 = a.nn[0] / 60; const int rem = a.nn[0] - 60 * a.n64;
+  a.has32 = 0;
+  if (rem > 28) a.n64 += 1; else if (rem > 0) a.has32 = 1;
+  if (a.n64 == 0 && !a.has32) a.has32 = 1;
+  a.x0_32 = 60 * a.n64 - 2;
+  a.nty64 = (a.nn[1] + 11) / 12; a.nty32 = (a.nn[1] + 27) / 28;
   // z-chunks: as many workgroups as fit the chip in ONE round (one 1024-thread workgroup per CU), an even number of planes each
-  const int cols = a.ntx * a.nty;
+  const int cols = a.n64 * a.nty64 + a.has32 * a.nty32;
   int nzc = n_cus / cols; if (nzc < 1) nzc = 1;
   int chunk = (a.nn[2] + nzc - 1) / nzc; chunk += chunk & 1; if (chunk < 8) chunk = 8;
   a.chunk = chunk; a.nzc = (a.nn[2] + chunk - 1) / chunk;
+  a.nA = a.n64 * a.nty64 * a.nzc; a.nblocks = a.nA + a.has32 * a.nty32 * a.nzc;
   const double lam = m.lam, G = m.G, l2g = lam + 2 * G, c[4] = {-(lam + G), lam - G, G - lam, lam + G};
   const double sM[3] = {m.box.h[0] / 30, m.box.h[1] / 30, m.box.h[2] / 30}, sK[3] = {1 / (3 * m.box.h[0]), 1 / (3 * m.box.h[1]), 1 / (3 * m.box.h[2])}, sC = 1.0 / 6;
   KronConsts &k = a.k;
@@ -295,10 +331,10 @@ void kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool
   k.m_gKyMz = G * sK[1] * sM[0] * sM[2]; k.m_gMyKz = G * sM[1] * sM[0] * sK[2]; k.m_lKyMz = l2g * sK[1] * sM[0] * sM[2]; k.m_lMyKz = l2g * sM[1] * sM[0] * sK[2];
   for (int i = 0; i < 4; ++i) { k.cc_mz[i] = c[i] * sC * sC * sM[2]; k.cc_oz[i] = c[i] * sM[1] * sC * sC; k.cc_mx[i] = c[i] * sC * sM[0] * sC; }
   a.nodemask = m.nodemask; a.constrained = constrained ? 1 : 0; a.mask_anywhere = m.mask_anywhere;
-  const size_t lds = (size_t)NFLD * TYR * TXN * sizeof(double);
+  const size_t lds = (size_t)NFLD * kTileNodes * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) { PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-  const int nblk = a.ntx * a.nty * a.nzc;
+  const int nblk = a.nblocks;
   // one Dirichlet dof per thread when the partial slots allow it (the list kernel is latency-bound)
   const int nfix = (constrained && m.n_dirichlet) ? (int)std::min<int64_t>((m.n_dirichlet + 255) / 256, dot_partials ? std::max(1, kMaxPartials - nblk) : 4096) : 0;
   if (dot_partials && nblk + nfix > kMaxPartials) throw Error("kron_apply: too many workgroups for the fused dot product");
