@@ -164,14 +164,15 @@ def main():
     avg_apply = t_apply / max(n_apply, 1)
     alg_bytes = bytes_per_apply(dim, deg, P.desc.n_dofs_u, P.desc.n_cells, "matrix_free")
     achieved = alg_bytes / avg_apply / 1e9 if n_apply else 0.0
-    kernel_time = {k: G.timer(k) for k in ("apply_u_matrix_free", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr",
+    t_fix, n_fix = G.timer("apply_u_dirichlet_rows")
+    kernel_time = {k: G.timer(k) for k in ("apply_u_matrix_free", "apply_u_dirichlet_rows", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr",
                                            "halo_exchange", "allreduce")}
 
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     # tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py); null when no profile is committed
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_kron_v2.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_kron_v3.json")) as f:
             traffic = json.load(f)["poro::k_kron3_q2"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -187,9 +188,10 @@ def main():
                        "stopping_rule_u": f"recursive residual <= max(1e-12, {args.rel_tol:g}*||b||), cap {args.max_iter}"},
             "roofline": {"bound": "hbm", "kernel": "k_kron3_q2 (matrix-free y = A_u x, sum-factorised)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e6 * avg_apply, "launches_timed": n_apply},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e6 * avg_apply, "launches_timed": n_apply,
+                         "note": "k_kron3_q2 alone (as rocprofv3 reports it); the Dirichlet rows are finished by the list kernel k_kron_fix_constrained, avg %.1f us per operator application" % (1e6 * t_fix / max(n_fix, 1))},
             "work_per_step": {k: work[k] / args.steps for k in work},
-            "kernel_only": {"apply_u_DoF_updates_per_s": (P.desc.n_dofs_u / avg_apply) if n_apply else 0.0,
+            "kernel_only": {"apply_u_DoF_updates_per_s": (P.desc.n_dofs_u / (avg_apply + t_fix / max(n_fix, 1))) if n_apply else 0.0,
                             "seconds_by_family": {k: v[0] for k, v in kernel_time.items()}, "launches_by_family": {k: v[1] for k, v in kernel_time.items()}},
             "fss_iterations_per_step": [int(len(t)) for t in traces],
         }

@@ -166,6 +166,7 @@ void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
-void kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr);
+int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr);   // returns the workgroup count (= partial slots used)
+void kron_fix_constrained(hipStream_t s, const MfArgs &a, const double *x, double *y, double *dot_partials, int slot_base);
 
 }  // namespace poro

@@ -188,7 +188,7 @@ MfArgs mf_args(poro_ctx *c) {
 }
 // y = A_u x without forming A_u: sum-factorised sweeps where available, element-matrix gather otherwise
 void mf_operator(poro_ctx *c, const double *x, double *y, bool constrained) {
-  if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) kron_apply(c->stream, mf_args(c), x, y, constrained, c->n_cus);
+  if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) { const int slots = kron_apply(c->stream, mf_args(c), x, y, constrained, c->n_cus); if (constrained) kron_fix_constrained(c->stream, mf_args(c), x, y, nullptr, slots); }
   else mf_apply(c->stream, mf_args(c), x, y, constrained);
 }
 
@@ -204,12 +204,15 @@ bool is_u_vec(int which) { return which == PORO_VEC_U || which == PORO_VEC_RHS_U
 // by the operator kernel itself (fused), false when the caller still has to launch the dot kernel.
 bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr) {
   bool fused = false;
-  {
+  if (mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
+    int slots;
+    { Timed tm(c, "apply_u_matrix_free"); slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials); }
+    { Timed tm(c, "apply_u_dirichlet_rows"); kron_fix_constrained(c->stream, mf_args(c), x, y, dot_partials, slots); }
+    fused = dot_partials != nullptr;
+  } else {
     Timed tm(c, mode == PORO_OP_MATRIX_FREE ? "apply_u_matrix_free" : "apply_u_csr");
-    if (mode == PORO_OP_MATRIX_FREE) {
-      if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) { kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials); fused = dot_partials != nullptr; }
-      else mf_apply(c->stream, mf_args(c), x, y, true);
-    } else la_csr_spmv(c->stream, c->Au, c->Au_val.p, x, y);
+    if (mode == PORO_OP_MATRIX_FREE) mf_apply(c->stream, mf_args(c), x, y, true);
+    else la_csr_spmv(c->stream, c->Au, c->Au_val.p, x, y);
   }
   exchange_add(c, y, c->n_u, c->comm.part.plane_u);
   return fused;

@@ -306,7 +306,7 @@ void check_q2_element_matrices() {
 
 bool kron_supported(int dim, int k_u) { return dim == 3 && k_u == 2; }
 
-void kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials) {
+int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials) {
   static bool checked = false;
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
@@ -335,12 +335,19 @@ void kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool
   static bool attr_set = false;
   if (!attr_set) { PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
   const int nblk = a.nblocks;
-  // one Dirichlet dof per thread when the partial slots allow it (the list kernel is latency-bound)
-  const int nfix = (constrained && m.n_dirichlet) ? (int)std::min<int64_t>((m.n_dirichlet + 255) / 256, dot_partials ? std::max(1, kMaxPartials - nblk) : 4096) : 0;
-  if (dot_partials && nblk + nfix > kMaxPartials) throw Error("kron_apply: too many workgroups for the fused dot product");
+  if (dot_partials && nblk > kMaxPartials / 2) throw Error("kron_apply: too many workgroups for the fused dot product");
   a.dot_partials = dot_partials;
   hipLaunchKernelGGL(k_kron3_q2, (unsigned)nblk, 1024, lds, s, a, x, y);
-  if (nfix) hipLaunchKernelGGL(k_kron_fix_constrained, (unsigned)nfix, 256, 0, s, m.n_dirichlet, m.dirichlet_dofs, m.diag_local, x, y, dot_partials ? dot_partials + nblk : (double *)nullptr);
+  return nblk;
+}
+
+// Dirichlet rows of y = A_c x after kron_apply (separate launch so that profiles attribute it separately); slot_base = first free
+// partial slot (the return value of kron_apply) when the dot product is fused
+void kron_fix_constrained(hipStream_t s, const MfArgs &m, const double *x, double *y, double *dot_partials, int slot_base) {
+  if (!m.n_dirichlet) return;
+  // one Dirichlet dof per thread when the partial slots allow it (the list kernel is latency-bound)
+  const int nfix = (int)std::min<int64_t>((m.n_dirichlet + 255) / 256, dot_partials ? std::max(1, kMaxPartials - slot_base) : 4096);
+  hipLaunchKernelGGL(k_kron_fix_constrained, (unsigned)nfix, 256, 0, s, m.n_dirichlet, m.dirichlet_dofs, m.diag_local, x, y, dot_partials ? dot_partials + slot_base : (double *)nullptr);
 }
 
 }  // namespace poro
