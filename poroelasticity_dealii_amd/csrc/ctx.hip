@@ -549,7 +549,13 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (c->jac_dt < 0) throw Error("pres_solve before pres_assemble_jacobian");
-    auto apply = [&](const double *x, double *y, double *) { { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); } exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false; };
+    const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;   // uniform box: J is a constant-coefficient stencil
+    const double ja = 1. / c->mat.biot_M / c->jac_dt, jk = c->mat.k_over_mu;
+    auto apply = [&](const double *x, double *y, double *) {
+      if (stencil) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(c->stream, c->dim, c->box, ja, jk, x, y); }
+      else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); }
+      exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
+    };
     return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->diag_J.p, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
   });
 }
@@ -594,7 +600,12 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
     PORO_HIP(hipSetDevice(c->device));
     if (!c->projection_matrix_ready) throw Error("proj_solve before proj_assemble_matrix");
     if (entry < 0 || entry >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
-    auto apply = [&](const double *x, double *y, double *) { { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); } exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false; };
+    const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;
+    auto apply = [&](const double *x, double *y, double *) {
+      if (stencil) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(c->stream, c->dim, c->box, 1.0, 0.0, x, y); }
+      else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); }
+      exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
+    };
     return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->diag_M.p, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
   });
 }

@@ -231,3 +231,33 @@ def test_sum_factorised_operator_equals_element_matrix_operator(n, monkeypatch):
     assert rel(ys[0][0], ys[1][0]) <= 1e-12
     assert rel(ys[0][1], ys[1][1]) <= 1e-12
     P.close()
+
+
+@pytest.mark.parametrize("dim,n", [(2, (9, 6)), (3, (4, 3, 5)), (3, 6)], ids=str)
+def test_structured_pressure_operator(dim, n):
+    """matrix-free contexts apply the pressure Jacobian / projection mass matrix as constant-coefficient stencils (k_p_stencil);
+    the solves must land on the oracle's CSR solves (pressure increment and projected strains, 1e-9 in l2)."""
+    P = box_problem(dim, n, 1)
+    O = oracle_py.Oracle(P, hoisted=True)
+    G = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    try:
+        npp = G.n_p
+        vals = {pk.VEC_P: 10e6 * (1 + 0.05 * synth(npp)), pk.VEC_P_OLD: 10e6 * (1 + 0.05 * synth(npp, 0.2)), pk.VEC_EPSV: -2e-6 * (1 + 0.3 * synth(npp, 0.5)),
+                pk.VEC_EPSV0: -2e-6 * np.ones(npp), pk.VEC_DP: 1e3 * synth(npp, 0.7)}
+        for k, v in vals.items():
+            O.set(k, v); G.set(k, v)
+        r0, r1 = O.pres_assemble_residual(60.0), G.pres_assemble_residual(60.0)
+        assert abs(r1 - r0) <= 1e-12 * r0
+        O.pres_assemble_jacobian(60.0); G.pres_assemble_jacobian(60.0)
+        rc0, _ = O.pres_solve(rel_tol=1e-13); rc, _ = G.pres_solve(rel_tol=1e-13)
+        assert rc0 == 0 and rc == 0
+        assert rel2(G.get(pk.VEC_DP), O.get(pk.VEC_DP)) <= 1e-9
+        u = 1e-5 * synth(G.n_u, 0.13)
+        O.set(pk.VEC_U, u); G.set(pk.VEC_U, u)
+        comps = [a * dim + a for a in range(dim)]
+        O.proj_assemble_matrix(); G.proj_assemble_matrix(); O.proj_assemble_rhs(comps); G.proj_assemble_rhs(comps)
+        for e in ([0, 2] if dim == 2 else [0, 3, 5]):
+            assert O.proj_solve(e, rel_tol=1e-13)[0] == 0 and G.proj_solve(e, rel_tol=1e-13)[0] == 0
+            assert rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
+    finally:
+        G.close(); O.close(); P.close()
