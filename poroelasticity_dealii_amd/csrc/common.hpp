@@ -36,7 +36,7 @@ constexpr int kScalarSlots = 32;
 // device-resident scalars of a PCG solve (no host round trip inside the iteration)
 struct PcgScalars {
   double dh, gg, gz;         // reductions of the current iteration (after all-reduce)
-  double gh2[2];             // g.z of the previous iteration (ping-pong by iteration parity in the fused path; [0] otherwise)
+  double gh2[2];             // g.z of the previous iteration (ping-pong by iteration parity)
   double alpha, beta;
   double tol, res0, res;
   int32_t it, done, converged, max_iter;
@@ -127,19 +127,15 @@ void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const doubl
 // PCG pieces (device-side control, see solver in ctx.hip)
 void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, int64_t n);
 void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials);
-void pcg_update_xg(hipStream_t s, const PcgScalars *sc, double *x, double *g, const double *d, const double *h, const double *diag, int prec,
-                   int64_t n, int64_t n_owned, double *partials /*2 sets*/);
-void pcg_update_d(hipStream_t s, const PcgScalars *sc, double *d, const double *g, const double *diag, int prec, int64_t n);
 void pcg_first_direction(hipStream_t s, double *d, const double *g, const double *diag, int prec, int64_t n, int64_t n_owned, double *partials /*2 sets: gg, gz*/);
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red);
 void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red /*bb, gg, gz*/, double abs_tol, double rel_tol, int max_iter);
-void pcg_scalars_alpha(hipStream_t s, PcgScalars *sc, const double *red /*dh*/);
-void pcg_scalars_beta(hipStream_t s, PcgScalars *sc, const double *red /*gg, gz*/);
 // single-rank fast path: the consumers reduce the block partials themselves (no scalar kernels, no host round trip);
 // parity = iteration index & 1 selects the g.z slot read / written
 void pcg_update_xg_fused(hipStream_t s, PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec,
-                         int64_t n, const double *partials_dh, double *partials_out /*2 sets*/);
-void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in /*2 sets*/);
+                         int64_t n, int64_t n_owned, const double *partials_dh, const double *red /*null: single rank*/, double *partials_out /*2 sets*/);
+void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n,
+                        const double *partials_in /*2 sets*/, const double *red /*null: single rank*/);
 
 // ---- kernels_asm.hip ----------------------------------------------------------------------------
 struct AsmArgs {

@@ -219,8 +219,8 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
 }
 
 // ---- PCG with device-side control: SolverCG<>::solve restated, Jacobi instead of SSOR ---------------
-// apply(x, y, dot_partials) as apply_A_u.  Single rank: the vector kernels reduce the block partials in their prologues (3 launches
-// per iteration incl. the operator); partitioned: explicit sums + all-reduces between the kernels.
+// apply(x, y, dot_partials) as apply_A_u.  The vector kernels compute alpha / beta / the stopping test in their prologues: from the
+// block partials (single rank, 3 launches per iteration incl. the operator) or from the all-reduced scalars (partitioned).
 int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
         const double *diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
   hipStream_t s = c->stream;
@@ -247,21 +247,14 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
     if (hs.done) break;
     for (int k = 0; k < batch; ++k) {
       ++it;
-      if (!multi) {
-        if (!apply(d, h, part_dh)) pcg_dot_dh(s, sc, d, h, n, part_dh);
-        ++applies;
-        pcg_update_xg_fused(s, sc, (it - 1) & 1, x, g, d, h, diag, prec, n, part_dh, part);
-        pcg_update_d_fused(s, sc, (it - 1) & 1, it, d, g, diag, prec, n, part);
-      } else {
-        apply(d, h, nullptr); ++applies;
-        pcg_dot_dh(s, sc, d, h, n_own, part);
-        pcg_scalars_sum(s, part, 1, red); allreduce_sum(c, red, 1);
-        pcg_scalars_alpha(s, sc, red);
-        pcg_update_xg(s, sc, x, g, d, h, diag, prec, n, n_own, part);
-        pcg_scalars_sum(s, part, 2, red); allreduce_sum(c, red, 2);
-        pcg_scalars_beta(s, sc, red);
-        pcg_update_d(s, sc, d, g, diag, prec, n);
-      }
+      // operator (+ fused or separate d.h partials).  A fused dot runs over ALL local rows of the pre-exchange partial product, which
+      // sums to the global d.Ad over the ranks; the separate kernel sees the exchanged h and therefore skips the upper shared plane.
+      if (!apply(d, h, part_dh)) pcg_dot_dh(s, sc, d, h, n_own, part_dh);
+      ++applies;
+      if (multi) { pcg_scalars_sum(s, part_dh, 1, red); allreduce_sum(c, red, 1); }
+      pcg_update_xg_fused(s, sc, (it - 1) & 1, x, g, d, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
+      if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
+      pcg_update_d_fused(s, sc, (it - 1) & 1, it, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
     if (batch < 32) batch *= 2;
   }

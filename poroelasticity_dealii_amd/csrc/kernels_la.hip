@@ -170,28 +170,6 @@ __global__ void k_pcg_dot_dh(const PcgScalars *sc, const double *d, const double
   s = block_sum(s, sh);
   store_partial(partials, s);
 }
-__global__ void k_pcg_update_xg(const PcgScalars *sc, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
-                                int64_t n_owned, double *partials) {
-  __shared__ double sh[4];
-  if (sc->done) return;
-  const double alpha = sc->alpha;
-  double gg = 0, gz = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double gi = g[i] + alpha * h[i];
-    g[i] = gi; x[i] += alpha * d[i];
-    if (i < n_owned) { const double z = prec ? gi / diag[i] : gi; gg += gi * gi; gz += gi * z; }
-  }
-  gg = block_sum(gg, sh); gz = block_sum(gz, sh);
-  store_partial(partials, gg); store_partial(partials + kMaxPartials, gz);
-}
-__global__ void k_pcg_update_d(const PcgScalars *sc, double *d, const double *g, const double *diag, int prec, int64_t n) {
-  if (sc->done) return;
-  const double beta = sc->beta;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double gi = g[i], z = prec ? gi / diag[i] : gi;
-    d[i] = beta * d[i] - z;
-  }
-}
 __global__ void k_scalars_sum(const PcgScalars *sc, const double *partials, int n_sets, double *red) {
   __shared__ double sh[4];
   if (sc && sc->done) return;
@@ -210,19 +188,6 @@ __global__ void k_scalars_start(PcgScalars *sc, const double *red, double abs_to
   sc->it = 0; sc->max_iter = max_iter;
   sc->converged = sc->res <= sc->tol; sc->done = sc->converged;
 }
-__global__ void k_scalars_alpha(PcgScalars *sc, const double *red) {
-  if (sc->done) return;
-  sc->dh = red[0]; sc->alpha = sc->gh2[0] / red[0];
-}
-__global__ void k_scalars_beta(PcgScalars *sc, const double *red) {
-  if (sc->done) return;
-  const double gg = red[0], gz = red[1];
-  sc->it += 1; sc->gg = gg; sc->gz = gz; sc->res = sqrt(gg);
-  if (sc->res <= sc->tol) { sc->done = 1; sc->converged = 1; return; }        // SolverControl::success
-  if (sc->it >= sc->max_iter) { sc->done = 1; sc->converged = 0; return; }    // SolverControl::failure -> NoConvergence
-  sc->beta = gz / sc->gh2[0]; sc->gh2[0] = gz;
-}
-
 // sum of kMaxPartials block partials in a fixed order, broadcast to every thread of the block (identical bits in every block)
 __device__ inline double sum_partials(const double *p, double *sh /*[5]*/) {
   double v = 0;
@@ -234,17 +199,18 @@ __device__ inline double sum_partials(const double *p, double *sh /*[5]*/) {
   __syncthreads();
   return v;
 }
+// red != null (partitioned run): the all-reduced scalars are read instead of the local block partials
 __global__ void k_pcg_update_xg_fused(PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
-                                      const double *partials_dh, double *partials_out) {
+                                      int64_t n_owned, const double *partials_dh, const double *red, double *partials_out) {
   __shared__ double sh[5];
   if (sc->done) return;
-  const double dh = sum_partials(partials_dh, sh);
+  const double dh = red ? red[0] : sum_partials(partials_dh, sh);
   const double alpha = sc->gh2[parity] / dh;
   double gg = 0, gz = 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const double gi = g[i] + alpha * h[i];
     g[i] = gi; x[i] += alpha * d[i];
-    const double z = prec ? gi / diag[i] : gi; gg += gi * gi; gz += gi * z;
+    if (i < n_owned) { const double z = prec ? gi / diag[i] : gi; gg += gi * gi; gz += gi * z; }
   }
   gg = block_sum(gg, sh); gz = block_sum(gz, sh);
   store_partial(partials_out, gg); store_partial(partials_out + kMaxPartials, gz);
@@ -252,10 +218,10 @@ __global__ void k_pcg_update_xg_fused(PcgScalars *sc, int parity, double *x, dou
 }
 // `it` = 1-based index of this iteration, supplied by the host (launch order), so no block depends on a control word that
 // another block of the same launch updates; only block 0 writes the control words
-__global__ void k_pcg_update_d_fused(PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in) {
+__global__ void k_pcg_update_d_fused(PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in, const double *red) {
   __shared__ double sh[5];
   if (sc->done) return;
-  const double gg = sum_partials(partials_in, sh), gz = sum_partials(partials_in + kMaxPartials, sh);
+  const double gg = red ? red[0] : sum_partials(partials_in, sh), gz = red ? red[1] : sum_partials(partials_in + kMaxPartials, sh);
   const double res = sqrt(gg), gh_old = sc->gh2[parity];
   const bool conv = res <= sc->tol, fail = !conv && it >= sc->max_iter;      // SolverControl::check order: success first, then the cap
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gg = gg; sc->gz = gz; sc->res = res; sc->it = it; }
@@ -342,13 +308,6 @@ void pcg_first_direction(hipStream_t s, double *d, const double *g, const double
 void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials) {
   hipLaunchKernelGGL(k_pcg_dot_dh, reduce_grid(n_owned), kBlock, 0, s, sc, d, h, n_owned, partials);
 }
-void pcg_update_xg(hipStream_t s, const PcgScalars *sc, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
-                   int64_t n_owned, double *partials) {
-  hipLaunchKernelGGL(k_pcg_update_xg, reduce_grid(n), kBlock, 0, s, sc, x, g, d, h, diag, prec, n, n_owned, partials);
-}
-void pcg_update_d(hipStream_t s, const PcgScalars *sc, double *d, const double *g, const double *diag, int prec, int64_t n) {
-  hipLaunchKernelGGL(k_pcg_update_d, grid_for(n), kBlock, 0, s, sc, d, g, diag, prec, n);
-}
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red) {
   hipLaunchKernelGGL(k_scalars_sum, 1, kBlock, 0, s, (const PcgScalars *)nullptr, partials, n_sets, red);
 }
@@ -356,13 +315,11 @@ void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red, double 
   hipLaunchKernelGGL(k_scalars_start, 1, 1, 0, s, sc, red, abs_tol, rel_tol, max_iter);
 }
 void pcg_update_xg_fused(hipStream_t s, PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
-                         const double *partials_dh, double *partials_out) {
-  hipLaunchKernelGGL(k_pcg_update_xg_fused, reduce_grid(n), kBlock, 0, s, sc, parity, x, g, d, h, diag, prec, n, partials_dh, partials_out);
+                         int64_t n_owned, const double *partials_dh, const double *red, double *partials_out) {
+  hipLaunchKernelGGL(k_pcg_update_xg_fused, reduce_grid(n), kBlock, 0, s, sc, parity, x, g, d, h, diag, prec, n, n_owned, partials_dh, red, partials_out);
 }
-void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in) {
-  hipLaunchKernelGGL(k_pcg_update_d_fused, reduce_grid(n), kBlock, 0, s, sc, parity, it, d, g, diag, prec, n, partials_in);
+void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in,
+                        const double *red) {
+  hipLaunchKernelGGL(k_pcg_update_d_fused, reduce_grid(n), kBlock, 0, s, sc, parity, it, d, g, diag, prec, n, partials_in, red);
 }
-void pcg_scalars_alpha(hipStream_t s, PcgScalars *sc, const double *red) { hipLaunchKernelGGL(k_scalars_alpha, 1, 1, 0, s, sc, red); }
-void pcg_scalars_beta(hipStream_t s, PcgScalars *sc, const double *red) { hipLaunchKernelGGL(k_scalars_beta, 1, 1, 0, s, sc, red); }
-
 }  // namespace poro
