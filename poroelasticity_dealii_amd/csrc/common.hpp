@@ -62,7 +62,8 @@ struct Comm {
   // host-staged callbacks (tests)
   poro_allreduce_fn ar = nullptr; poro_sendrecv_fn sr = nullptr; void *user = nullptr;
   DevBuf<double> recv_lo, recv_hi; std::vector<double> hsend, hrecv;
-  bool multi() const { return part.n_ranks > 1; }
+  bool force_multi = false;
+  bool multi() const { return part.n_ranks > 1 || force_multi; }
 };
 
 struct BoxDev { int enabled = 0; int n[3] = {1, 1, 1}; int nn[3] = {1, 1, 1}; double h[3] = {1, 1, 1}; };

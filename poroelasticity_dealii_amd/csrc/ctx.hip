@@ -272,6 +272,7 @@ void setup(poro_ctx *c, const poro_desc *d) {
   c->dim = d->dim; c->k_u = d->degree_u; c->nv = 1 << d->dim; c->ns_u = ipow(c->k_u + 1, c->dim); c->ns_p = c->nv; c->dpc_u = c->ns_u * c->dim; c->dpc_p = c->ns_p;
   c->n_cells = d->n_cells; c->n_u = d->n_dofs_u; c->n_p = d->n_dofs_p; c->mat = d->mat; c->comm.part = d->part;
   if (c->comm.part.n_ranks < 1) { c->comm.part.n_ranks = 1; c->comm.part.rank = 0; }
+  c->comm.force_multi = std::getenv("PORO_FORCE_PARTITIONED_PATH") != nullptr;   // test hook: run the partitioned code path on one rank
   const poro_fe_tables &f = d->fe;
   if (f.nq_u != ipow(c->k_u + 1, c->dim) || f.nq_p != c->nv || f.ns_u != c->ns_u || f.ns_p != c->ns_p || f.nq_f != ipow(c->k_u + 1, c->dim - 1)) throw Error("poro_fe_tables sizes do not match dim / degree");
   if (c->n_cells <= 0 || c->n_u <= 0 || c->n_p <= 0) throw Error("empty mesh");
@@ -408,7 +409,22 @@ int poro_ctx_comm_init_rccl(poro_ctx *c, const void *id128) {
     g_rccl.load(); PORO_HIP(hipSetDevice(c->device));
     ncclUniqueId id; std::memcpy(&id, id128, 128); ncclComm_t comm;
     PORO_NCCL(g_rccl.CommInitRank(&comm, c->comm.part.n_ranks, id, c->comm.part.rank));
-    c->comm.nccl_comm = comm; return 0;
+    c->comm.nccl_comm = comm;
+    // self-test of the data plane on the compute stream: an all-reduce of a known value and one grouped neighbour exchange
+    // (to itself when there is a single rank), so a broken RCCL set-up fails here with a message instead of inside a solve
+    const int nr = c->comm.part.n_ranks, rk = c->comm.part.rank;
+    DevBuf<double> t; t.alloc(4);
+    double h[4] = {1.0 + rk, 2.0, 100.0 + rk, -1.0};
+    PORO_HIP(hipMemcpyAsync(t.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    PORO_NCCL(g_rccl.AllReduce(t.p, t.p, 2, ncclFloat64, ncclSum, comm, c->stream));
+    const int up = (rk + 1) % nr, down = (rk + nr - 1) % nr;
+    PORO_NCCL(g_rccl.GroupStart());
+    PORO_NCCL(g_rccl.Send(t.p + 2, 1, ncclFloat64, up, comm, c->stream));
+    PORO_NCCL(g_rccl.Recv(t.p + 3, 1, ncclFloat64, down, comm, c->stream));
+    PORO_NCCL(g_rccl.GroupEnd());
+    PORO_HIP(hipMemcpyAsync(h, t.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+    if (h[0] != 0.5 * nr * (nr + 1) || h[1] != 2.0 * nr || h[3] != 100.0 + down) throw Error("RCCL self-test failed (all-reduce / send-recv returned wrong data)");
+    return 0;
   });
 }
 int poro_ctx_comm_init_callbacks(poro_ctx *c, poro_allreduce_fn ar, poro_sendrecv_fn sr, void *user) { c->comm.ar = ar; c->comm.sr = sr; c->comm.user = user; return 0; }

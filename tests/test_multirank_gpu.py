@@ -46,3 +46,22 @@ def test_two_ranks_on_one_gpu(tmp_path, dim, n, deg, backend):
     y = O.apply(pk.MAT_A_U, np.sin(0.11 * np.arange(P.desc.n_dofs_u)))
     assert np.abs(Ax - y).max() <= 1e-12 * np.abs(y).max()
     O.close(); P.close()
+
+
+def test_rccl_data_plane_single_rank(monkeypatch):
+    """RCCL plumbing on one GPU: dlopen, ncclCommInitRank(1 rank) + the library's communicator self-test (all-reduce, grouped
+    send/recv to itself), then a solve through the partitioned code path (explicit sums + ncclAllReduce on the compute stream)."""
+    monkeypatch.setenv("PORO_FORCE_PARTITIONED_PATH", "1")
+    P = box_problem(3, 4, 2)
+    O = oracle_py.Oracle(P, hoisted=True)
+    G = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    try:
+        G.comm_rccl(pk.rccl_unique_id())
+        p = 10e6 * (1 + 0.1 * np.sin(0.37 * np.arange(G.n_p)))
+        O.set(pk.VEC_P, p); G.set(pk.VEC_P, p)
+        O.disp_assemble_system(True); G.disp_assemble_system(True)
+        assert O.disp_solve()[0] == 0 and G.disp_solve(max_iter=5000)[0] == 0
+        assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+        assert abs(G.norm(pk.VEC_U)[0] - np.linalg.norm(O.get(pk.VEC_U))) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+    finally:
+        G.close(); O.close(); P.close()
