@@ -39,8 +39,12 @@ struct PcgScalars {
   double gh2[2];             // g.z of the previous iteration (ping-pong by iteration parity)
   double alpha, beta;
   double tol, res0, res;
-  int32_t it, done, converged, max_iter;
+  int32_t it, done, converged, max_iter, finishing, pad_;
 };
+
+// INVERSE Jacobi diagonal handed to the PCG kernels (they multiply): the full vector of reciprocals, or (uniform boxes) a class byte
+// per node + table[class][component] of reciprocals
+struct DiagVec { const double *full = nullptr; const uint8_t *cls = nullptr; const double *tab = nullptr; int ncomp = 1; };
 
 struct FeTablesDev {   // device copies of poro_fe_tables
   int nq_u, nq_p, nq_f, ns_u, ns_p;
@@ -95,6 +99,8 @@ struct poro_ctx {
   // vectors (ids of include/poroel_hip.h)
   std::map<int, poro::DevBuf<double>> vec;
   poro::DevBuf<double> lift_u, neumann_u, diag_u, diag_u_local, diag_J, diag_M, src_local;
+  poro::DevBuf<double> dinv_u, dinv_J, dinv_M;   // reciprocals of the Jacobi diagonals
+  poro::DevBuf<uint8_t> diag_u_cls; poro::DevBuf<double> diag_u_tab;   // dictionary form of diag_u (uniform boxes): class per node + table[class][dim]
   poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
@@ -122,20 +128,21 @@ void la_csr_residual(hipStream_t s, const CsrDev &A, const double *M, const doub
 void la_pressure_tmp(hipStream_t s, double *t, const double *ev, const double *ev0, const double *p, const double *p_old, double c1, double c2, int64_t n);
 void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, double a, double kappa, int64_t nnz);
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag);
+void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n);
 void la_sum_strains(hipStream_t s, double *ev, const double *const *strains, int n, int64_t len);
 void la_set_constrained(hipStream_t s, double *x, const uint8_t *mask, const double *val, int64_t n);
 void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const double *neumann, const uint8_t *mask, int64_t n);
 // PCG pieces (device-side control, see solver in ctx.hip)
 void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, int64_t n);
 void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials);
-void pcg_first_direction(hipStream_t s, double *d, const double *g, const double *diag, int prec, int64_t n, int64_t n_owned, double *partials /*2 sets: gg, gz*/);
+void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVec &diag, int prec, int64_t n, int64_t n_owned, double *partials /*2 sets: gg, gz*/);
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red);
 void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red /*bb, gg, gz*/, double abs_tol, double rel_tol, int max_iter);
 // single-rank fast path: the consumers reduce the block partials themselves (no scalar kernels, no host round trip);
 // parity = iteration index & 1 selects the g.z slot read / written
-void pcg_update_xg_fused(hipStream_t s, PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec,
-                         int64_t n, int64_t n_owned, const double *partials_dh, const double *red /*null: single rank*/, double *partials_out /*2 sets*/);
-void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n,
+void pcg_update_g_fused(hipStream_t s, PcgScalars *sc, int parity, double *g, const double *h, const DiagVec &diag, int prec, int64_t n, int64_t n_owned,
+                        const double *partials_dh, const double *red /*null: single rank*/, double *partials_out /*2 sets*/);
+void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *x, double *d, const double *g, const DiagVec &diag, int prec, int64_t n,
                         const double *partials_in /*2 sets*/, const double *red /*null: single rank*/);
 
 // ---- kernels_asm.hip ----------------------------------------------------------------------------

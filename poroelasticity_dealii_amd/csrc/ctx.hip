@@ -4,12 +4,14 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
+#include <unordered_map>
 #include "common.hpp"
 
 using namespace poro;
@@ -222,7 +224,7 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
 // apply(x, y, dot_partials) as apply_A_u.  The vector kernels compute alpha / beta / the stopping test in their prologues: from the
 // block partials (single rank, 3 launches per iteration incl. the operator) or from the all-reduced scalars (partitioned).
 int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
-        const double *diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
+        const DiagVec &diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
   hipStream_t s = c->stream;
   const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
   const int64_t n_own = owned(c, n, plane);
@@ -244,7 +246,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   int batch = 4, it = 0;
   while (true) {
     PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
-    if (hs.done) break;
+    if (hs.done || hs.finishing) break;
     for (int k = 0; k < batch; ++k) {
       ++it;
       // operator (+ fused or separate d.h partials).  A fused dot runs over ALL local rows of the pre-exchange partial product, which
@@ -252,9 +254,9 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
       if (!apply(d, h, part_dh)) pcg_dot_dh(s, sc, d, h, n_own, part_dh);
       ++applies;
       if (multi) { pcg_scalars_sum(s, part_dh, 1, red); allreduce_sum(c, red, 1); }
-      pcg_update_xg_fused(s, sc, (it - 1) & 1, x, g, d, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
+      pcg_update_g_fused(s, sc, (it - 1) & 1, g, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
       if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
-      pcg_update_d_fused(s, sc, (it - 1) & 1, it, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
+      pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
     if (batch < 32) batch *= 2;
   }
@@ -494,6 +496,25 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
       if (!c->diag_u.p) c->diag_u.alloc(c->n_u);
       la_copy(s, c->diag_u.p, c->diag_u_local.p, c->n_u);
       exchange_add(c, c->diag_u.p, c->n_u, c->comm.part.plane_u);
+      // dictionary form of the Jacobi diagonal: on a uniform box only a few dozen distinct per-node triples exist, so the PCG kernels
+      // can read one class byte per node and a tiny table instead of 8 bytes per dof.  Built by de-duplicating the actual values.
+      c->diag_u_cls.release(); c->diag_u_tab.release();
+      if (!c->dinv_u.p) c->dinv_u.alloc(c->n_u);
+      la_reciprocal(s, c->dinv_u.p, c->diag_u.p, c->n_u);
+      if (c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled) {
+        std::vector<double> hd(c->n_u);
+        PORO_HIP(hipMemcpyAsync(hd.data(), c->diag_u.p, c->n_u * sizeof(double), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+        const int nc = c->dim; const int64_t nnode = c->n_u / nc;
+        struct KeyHash { size_t operator()(const std::array<double, 3> &k) const { uint64_t h = 1469598103934665603ull; for (double v : k) { uint64_t b; std::memcpy(&b, &v, 8); h = (h ^ b) * 1099511628211ull; h ^= h >> 29; } return (size_t)h; } };
+        std::unordered_map<std::array<double, 3>, int, KeyHash> dict; std::vector<uint8_t> cls(nnode); std::vector<double> tab; bool ok = true;
+        for (int64_t nd = 0; nd < nnode && ok; ++nd) {
+          std::array<double, 3> key{0, 0, 0}; for (int k = 0; k < nc; ++k) key[k] = hd[nd * nc + k];
+          auto it = dict.find(key);
+          if (it == dict.end()) { if (dict.size() >= 255) { ok = false; break; } it = dict.emplace(key, (int)dict.size()).first; for (int k = 0; k < nc; ++k) tab.push_back(1.0 / key[k]); }
+          cls[nd] = (uint8_t)it->second;
+        }
+        if (ok) { c->diag_u_cls.upload(cls); c->diag_u_tab.upload(tab); }
+      }
       c->matrix_built = true;
     }
     {
@@ -516,7 +537,9 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
     auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp); };
-    const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->diag_u.p, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
+    DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim;
+    if (c->diag_u_cls.p) { dv.cls = c->diag_u_cls.p; dv.tab = c->diag_u_tab.p; }
+    const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dv, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
     la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);   // constraints.distribute (:306)
     PORO_HIP(hipStreamSynchronize(c->stream));
     return rc;
@@ -549,6 +572,8 @@ int poro_pres_assemble_jacobian(poro_ctx *c, double dt) {
     la_jacobian(c->stream, c->Jp.p, c->Mp.p, c->Kp.p, 1. / c->mat.biot_M / dt, c->mat.k_over_mu, c->Ap.nnz);
     la_csr_diag(c->stream, c->Ap, c->Jp.p, c->diag_J.p);
     exchange_add(c, c->diag_J.p, c->n_p, c->comm.part.plane_p);
+    if (!c->dinv_J.p) c->dinv_J.alloc(c->n_p);
+    la_reciprocal(c->stream, c->dinv_J.p, c->diag_J.p, c->n_p);
     c->jac_dt = dt;
     return 0;
   });
@@ -565,7 +590,8 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); }
       exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
     };
-    return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->diag_J.p, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    DiagVec dv; dv.full = c->dinv_J.p;
+    return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
   });
 }
 
@@ -578,6 +604,8 @@ int poro_proj_assemble_matrix(poro_ctx *c) {
     PORO_HIP(hipSetDevice(c->device));
     la_csr_diag(c->stream, c->Ap, c->Mp.p, c->diag_M.p);                       // projection_matrix = mass_matrix (StrainProjector.h:104)
     exchange_add(c, c->diag_M.p, c->n_p, c->comm.part.plane_p);
+    if (!c->dinv_M.p) c->dinv_M.alloc(c->n_p);
+    la_reciprocal(c->stream, c->dinv_M.p, c->diag_M.p, c->n_p);
     c->projection_matrix_ready = true; return 0;
   });
 }
@@ -615,7 +643,8 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
       else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); }
       exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
     };
-    return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->diag_M.p, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    DiagVec dv; dv.full = c->dinv_M.p;
+    return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
   });
 }
 

@@ -129,6 +129,9 @@ __global__ void k_pressure_tmp(double *t, const double *ev, const double *ev0, c
 __global__ void k_jacobian(double *J, const double *M, const double *K, double a, double kappa, int64_t nnz) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * kBlock) J[i] = M[i] * a + kappa * K[i];
 }
+__global__ void k_reciprocal(double *y, const double *x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] = 1.0 / x[i];
+}
 __global__ void k_csr_diag(int64_t n, const int64_t *pos, const double *val, double *diag) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) diag[i] = val[pos[i]];
 }
@@ -148,14 +151,22 @@ __global__ void k_rhs_u_finish(double *rhs, const double *lift, const double *ne
 }
 
 // ---- PCG (deal.II SolverCG structure: g = A x - b, d = -P^-1 g) ----------------------------------
+// INVERSE Jacobi diagonal (z = g * dinv: no fp64 division in the streaming kernels) either as a full vector or
+// dictionary-compressed: class byte per node (ncomp dofs each) + table[class][comp]
+struct DiagRef { const double *full; const uint8_t *cls; const double *tab; int ncomp; };
+// NC = components per node of the dictionary form (0: full vector); NC is a template parameter so that i / NC is a multiply
+template <int NC> __device__ inline double diag_at(const DiagRef &D, int64_t i) {
+  if constexpr (NC == 0) return D.full[i];
+  else { const uint32_t node = (uint32_t)i / (uint32_t)NC; return D.tab[(uint32_t)D.cls[node] * NC + ((uint32_t)i - node * NC)]; }
+}
 __global__ void k_pcg_init_residual(double *g, const double *Ax, const double *b, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) g[i] = Ax[i] - b[i];
 }
-__global__ void k_pcg_first_direction(double *d, const double *g, const double *diag, int prec, int64_t n, int64_t n_owned, double *partials) {
+template <int NC> __global__ void k_pcg_first_direction(double *d, const double *g, DiagRef D, int prec, int64_t n, int64_t n_owned, double *partials) {
   __shared__ double sh[4];
   double gg = 0, gz = 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double gi = g[i], z = prec ? gi / diag[i] : gi;
+    const double gi = g[i], z = prec ? gi * diag_at<NC>(D, i) : gi;
     d[i] = -z;
     if (i < n_owned) { gg += gi * gi; gz += gi * z; }
   }
@@ -186,7 +197,7 @@ __global__ void k_scalars_start(PcgScalars *sc, const double *red, double abs_to
   sc->res0 = sc->res = sqrt(gg);
   sc->gg = gg; sc->gz = gz; sc->gh2[0] = gz; sc->gh2[1] = gz; sc->dh = 0; sc->alpha = 0; sc->beta = 0;
   sc->it = 0; sc->max_iter = max_iter;
-  sc->converged = sc->res <= sc->tol; sc->done = sc->converged;
+  sc->converged = sc->res <= sc->tol; sc->done = sc->converged; sc->finishing = 0;
 }
 // sum of kMaxPartials block partials in a fixed order, broadcast to every thread of the block (identical bits in every block)
 __device__ inline double sum_partials(const double *p, double *sh /*[5]*/) {
@@ -199,44 +210,52 @@ __device__ inline double sum_partials(const double *p, double *sh /*[5]*/) {
   __syncthreads();
   return v;
 }
-// red != null (partitioned run): the all-reduced scalars are read instead of the local block partials
-__global__ void k_pcg_update_xg_fused(PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
-                                      int64_t n_owned, const double *partials_dh, const double *red, double *partials_out) {
+// g += alpha h and the partials of g.g, g.z (z = g / diag).  red != null (partitioned run): the all-reduced scalars are read instead
+// of the local block partials.  x is NOT touched here: x += alpha d rides in k_pcg_update_d_fused, which reads d anyway.
+template <int NC> __global__ void k_pcg_update_g_fused(PcgScalars *sc, int parity, double *g, const double *h, DiagRef D, int prec, int64_t n, int64_t n_owned,
+                                     const double *partials_dh, const double *red, double *partials_out) {
   __shared__ double sh[5];
   if (sc->done) return;
+  // the previous iteration finished the solve: latch `done` here, one launch later, so that inside the finishing
+  // k_pcg_update_d_fused no block could see done = 1 and skip its share of the last x update
+  if (sc->finishing) { if (blockIdx.x == 0 && threadIdx.x == 0) sc->done = 1; return; }
   const double dh = red ? red[0] : sum_partials(partials_dh, sh);
   const double alpha = sc->gh2[parity] / dh;
   double gg = 0, gz = 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const double gi = g[i] + alpha * h[i];
-    g[i] = gi; x[i] += alpha * d[i];
-    if (i < n_owned) { const double z = prec ? gi / diag[i] : gi; gg += gi * gi; gz += gi * z; }
+    g[i] = gi;
+    if (i < n_owned) { const double z = prec ? gi * diag_at<NC>(D, i) : gi; gg += gi * gi; gz += gi * z; }
   }
   gg = block_sum(gg, sh); gz = block_sum(gz, sh);
   store_partial(partials_out, gg); store_partial(partials_out + kMaxPartials, gz);
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
 }
-// `it` = 1-based index of this iteration, supplied by the host (launch order), so no block depends on a control word that
-// another block of the same launch updates; only block 0 writes the control words
-__global__ void k_pcg_update_d_fused(PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in, const double *red) {
+// x += alpha d (always: SolverCG updates x before it checks the residual), then d = beta d - z unless the solve just finished.
+// `it` = 1-based index of this iteration, supplied by the host (launch order), so no block depends on a control word that another
+// block of the same launch updates; only block 0 writes the control words.
+template <int NC> __global__ void k_pcg_update_d_fused(PcgScalars *sc, int parity, int it, double *x, double *d, const double *g, DiagRef D, int prec, int64_t n,
+                                     const double *partials_in, const double *red) {
   __shared__ double sh[5];
   if (sc->done) return;
   const double gg = red ? red[0] : sum_partials(partials_in, sh), gz = red ? red[1] : sum_partials(partials_in + kMaxPartials, sh);
-  const double res = sqrt(gg), gh_old = sc->gh2[parity];
+  const double res = sqrt(gg), gh_old = sc->gh2[parity], alpha = sc->alpha;
   const bool conv = res <= sc->tol, fail = !conv && it >= sc->max_iter;      // SolverControl::check order: success first, then the cap
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gg = gg; sc->gz = gz; sc->res = res; sc->it = it; }
-  if (conv || fail) {   // every block takes this branch together (identical inputs); a block that starts late sees done = 1 and returns above
-    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->converged = conv ? 1 : 0; __threadfence(); sc->done = 1; }
+  if (conv || fail) {   // every block takes this branch together (identical inputs) and still owes its share of the last x update;
+                        // `done` itself is raised by the next launch (k_pcg_update_g_fused), never inside this one
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] += alpha * d[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->converged = conv ? 1 : 0; sc->finishing = 1; }
     return;
   }
   const double beta = gz / gh_old;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double gi = g[i], z = prec ? gi / diag[i] : gi;
-    d[i] = beta * d[i] - z;
+    const double gi = g[i], z = prec ? gi * diag_at<NC>(D, i) : gi, di = d[i];
+    x[i] += alpha * di;
+    d[i] = beta * di - z;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->gh2[parity ^ 1] = gz; }
 }
-
 template <class F> void dispatch_lanes(int L, F &&f) {
   switch (L) {
     case 2: f(std::integral_constant<int, 2>()); break;
@@ -286,6 +305,7 @@ void la_pressure_tmp(hipStream_t s, double *t, const double *ev, const double *e
 void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, double a, double kappa, int64_t nnz) {
   hipLaunchKernelGGL(k_jacobian, grid_for(nnz), kBlock, 0, s, J, M, K, a, kappa, nnz);
 }
+void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_reciprocal, grid_for(n), kBlock, 0, s, y, x, n); }
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag) {
   hipLaunchKernelGGL(k_csr_diag, grid_for(A.n), kBlock, 0, s, A.n, A.diag_pos.p, val, diag);
 }
@@ -299,11 +319,18 @@ void la_set_constrained(hipStream_t s, double *x, const uint8_t *mask, const dou
 void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const double *neu, const uint8_t *mask, int64_t n) {
   hipLaunchKernelGGL(k_rhs_u_finish, grid_for(n), kBlock, 0, s, rhs, lift, neu, mask, n);
 }
+// dictionary form only for 2 / 3 components and 32-bit dof indices
+static int diag_nc(const DiagVec &dv, int64_t n) { return (dv.cls && (dv.ncomp == 2 || dv.ncomp == 3) && n < (int64_t)4000000000ll) ? dv.ncomp : 0; }
 void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, int64_t n) {
   hipLaunchKernelGGL(k_pcg_init_residual, grid_for(n), kBlock, 0, s, g, Ax, b, n);
 }
-void pcg_first_direction(hipStream_t s, double *d, const double *g, const double *diag, int prec, int64_t n, int64_t n_owned, double *partials) {
-  hipLaunchKernelGGL(k_pcg_first_direction, reduce_grid(n), kBlock, 0, s, d, g, diag, prec, n, n_owned, partials);
+void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVec &dv, int prec, int64_t n, int64_t n_owned, double *partials) {
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp};
+  switch (diag_nc(dv, n)) {
+    case 2: hipLaunchKernelGGL(k_pcg_first_direction<2>, reduce_grid(n), kBlock, 0, s, d, g, D, prec, n, n_owned, partials); break;
+    case 3: hipLaunchKernelGGL(k_pcg_first_direction<3>, reduce_grid(n), kBlock, 0, s, d, g, D, prec, n, n_owned, partials); break;
+    default: hipLaunchKernelGGL(k_pcg_first_direction<0>, reduce_grid(n), kBlock, 0, s, d, g, D, prec, n, n_owned, partials);
+  }
 }
 void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials) {
   hipLaunchKernelGGL(k_pcg_dot_dh, reduce_grid(n_owned), kBlock, 0, s, sc, d, h, n_owned, partials);
@@ -314,12 +341,23 @@ void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *
 void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red, double abs_tol, double rel_tol, int max_iter) {
   hipLaunchKernelGGL(k_scalars_start, 1, 1, 0, s, sc, red, abs_tol, rel_tol, max_iter);
 }
-void pcg_update_xg_fused(hipStream_t s, PcgScalars *sc, int parity, double *x, double *g, const double *d, const double *h, const double *diag, int prec, int64_t n,
-                         int64_t n_owned, const double *partials_dh, const double *red, double *partials_out) {
-  hipLaunchKernelGGL(k_pcg_update_xg_fused, reduce_grid(n), kBlock, 0, s, sc, parity, x, g, d, h, diag, prec, n, n_owned, partials_dh, red, partials_out);
+void pcg_update_g_fused(hipStream_t s, PcgScalars *sc, int parity, double *g, const double *h, const DiagVec &dv, int prec, int64_t n, int64_t n_owned,
+                        const double *partials_dh, const double *red, double *partials_out) {
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp};
+  switch (diag_nc(dv, n)) {
+    case 2: hipLaunchKernelGGL(k_pcg_update_g_fused<2>, reduce_grid(n), kBlock, 0, s, sc, parity, g, h, D, prec, n, n_owned, partials_dh, red, partials_out); break;
+    case 3: hipLaunchKernelGGL(k_pcg_update_g_fused<3>, reduce_grid(n), kBlock, 0, s, sc, parity, g, h, D, prec, n, n_owned, partials_dh, red, partials_out); break;
+    default: hipLaunchKernelGGL(k_pcg_update_g_fused<0>, reduce_grid(n), kBlock, 0, s, sc, parity, g, h, D, prec, n, n_owned, partials_dh, red, partials_out);
+  }
 }
-void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *d, const double *g, const double *diag, int prec, int64_t n, const double *partials_in,
-                        const double *red) {
-  hipLaunchKernelGGL(k_pcg_update_d_fused, reduce_grid(n), kBlock, 0, s, sc, parity, it, d, g, diag, prec, n, partials_in, red);
+void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *x, double *d, const double *g, const DiagVec &dv, int prec, int64_t n,
+                        const double *partials_in, const double *red) {
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp};
+  switch (diag_nc(dv, n)) {
+    case 2: hipLaunchKernelGGL(k_pcg_update_d_fused<2>, reduce_grid(n), kBlock, 0, s, sc, parity, it, x, d, g, D, prec, n, partials_in, red); break;
+    case 3: hipLaunchKernelGGL(k_pcg_update_d_fused<3>, reduce_grid(n), kBlock, 0, s, sc, parity, it, x, d, g, D, prec, n, partials_in, red); break;
+    default: hipLaunchKernelGGL(k_pcg_update_d_fused<0>, reduce_grid(n), kBlock, 0, s, sc, parity, it, x, d, g, D, prec, n, partials_in, red);
+  }
 }
+
 }  // namespace poro
