@@ -222,11 +222,17 @@ template <int NC> __global__ void k_pcg_update_g_fused(PcgScalars *sc, int parit
   const double dh = red ? red[0] : sum_partials(partials_dh, sh);
   const double alpha = sc->gh2[parity] / dh;
   double gg = 0, gz = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double gi = g[i] + alpha * h[i];
-    g[i] = gi;
-    if (i < n_owned) { const double z = prec ? gi * diag_at<NC>(D, i) : gi; gg += gi * gi; gz += gi * z; }
+  auto one = [&](int64_t i, double gi) { if (i < n_owned) { const double z = prec ? gi * diag_at<NC>(D, i) : gi; gg += gi * gi; gz += gi * z; } };
+  // 16-byte accesses (two dofs per lane and step): the arrays are hipMalloc-aligned; an odd tail element goes to one thread
+  const int64_t n2 = n >> 1;
+  double2 *g2 = reinterpret_cast<double2 *>(g); const double2 *h2 = reinterpret_cast<const double2 *>(h);
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n2; q += (int64_t)gridDim.x * kBlock) {
+    double2 gv = g2[q]; const double2 hv = h2[q];
+    gv.x = fma(alpha, hv.x, gv.x); gv.y = fma(alpha, hv.y, gv.y);
+    g2[q] = gv;
+    one(2 * q, gv.x); one(2 * q + 1, gv.y);
   }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { const double gi = fma(alpha, h[n - 1], g[n - 1]); g[n - 1] = gi; one(n - 1, gi); }
   gg = block_sum(gg, sh); gz = block_sum(gz, sh);
   store_partial(partials_out, gg); store_partial(partials_out + kMaxPartials, gz);
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
@@ -244,15 +250,23 @@ template <int NC> __global__ void k_pcg_update_d_fused(PcgScalars *sc, int parit
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gg = gg; sc->gz = gz; sc->res = res; sc->it = it; }
   if (conv || fail) {   // every block takes this branch together (identical inputs) and still owes its share of the last x update;
                         // `done` itself is raised by the next launch (k_pcg_update_g_fused), never inside this one
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] += alpha * d[i];
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] = fma(alpha, d[i], x[i]);
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->converged = conv ? 1 : 0; sc->finishing = 1; }
     return;
   }
   const double beta = gz / gh_old;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double gi = g[i], z = prec ? gi * diag_at<NC>(D, i) : gi, di = d[i];
-    x[i] += alpha * di;
-    d[i] = beta * di - z;
+  const int64_t n2 = n >> 1;
+  double2 *x2 = reinterpret_cast<double2 *>(x), *d2 = reinterpret_cast<double2 *>(d); const double2 *g2 = reinterpret_cast<const double2 *>(g);
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n2; q += (int64_t)gridDim.x * kBlock) {
+    const double2 gv = g2[q]; double2 dv = d2[q], xv = x2[q];
+    const double z0 = prec ? gv.x * diag_at<NC>(D, 2 * q) : gv.x, z1 = prec ? gv.y * diag_at<NC>(D, 2 * q + 1) : gv.y;
+    xv.x = fma(alpha, dv.x, xv.x); xv.y = fma(alpha, dv.y, xv.y);
+    dv.x = fma(beta, dv.x, -z0); dv.y = fma(beta, dv.y, -z1);
+    x2[q] = xv; d2[q] = dv;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1; const double gi = g[i], z = prec ? gi * diag_at<NC>(D, i) : gi, di = d[i];
+    x[i] = fma(alpha, di, x[i]); d[i] = fma(beta, di, -z);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->gh2[parity ^ 1] = gz; }
 }
