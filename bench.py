@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--rel-tol", type=float, default=1e-10, help="displacement CG: recursive residual <= max(1e-12, rel_tol*||b||) (SURVEY §7 hard parts)")
     ap.add_argument("--max-iter", type=int, default=50000)
-    ap.add_argument("--cpu-n", type=int, default=8, help="cells per direction of the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=9, help="cells per direction of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
