@@ -268,6 +268,161 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   else { const int t = tile - a.nA; kron_tile<32>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
 }
 
+
+// ---- 3D Q1: the same construction with 3-point bands ---------------------------------------------------------------------------
+// FE_Q(1) 1D element matrices: M = (h/6) [[2,1],[1,2]], K = (1/h) [[1,-1],[-1,1]], C = (1/2) [[-1,-1],[1,1]]; assembled rows
+//   M (1, cM, 1), cM = 2(mL+mR);  K (-1, cK, -1), cK = mL+mR;  O (1, ., -1);  D = mL - mR.
+// Every node is a vertex node: 3-plane register window, one plane per barrier, halo of one node / row / plane.  Tiles: 64 lanes x 16
+// rows (62 x 14 valid) and 32 lanes x 32 rows (30 x 30 valid).
+template <int TXN>
+__device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__restrict__ x, double *__restrict__ y, double *L, const int X0, const int tyi, const int zc) {
+  constexpr int RPW = 64 / TXN, TYR = 16 * RPW, VY = TYR - 2;
+  const int tid = threadIdx.x;
+  const int NX = a.nn[0], NY = a.nn[1], NZ = a.nn[2];
+  const int Y0 = VY * tyi - 1;
+  const int k0 = zc * a.chunk, k1 = min(NZ, k0 + a.chunk);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lx = lane % TXN;
+  const int r = RPW == 1 ? w : w + 16 * (lane / TXN);
+  const bool halo_wave = RPW == 1 && (w == 0 || w == 15);        // (two rows per wave: halo rows share waves with valid rows)
+  const int j = Y0 + r, i = X0 + lx;
+  const bool vj = j >= 0 && j < NY, vn = vj && i >= 0 && i < NX;
+  const bool out = vn && lx >= 1 && lx <= TXN - 2 && r >= 1 && r <= TYR - 2;
+  const bool bnd_xy = i == 0 || i == NX - 1 || j == 0 || j == NY - 1;
+  const double mLx = i > 0 ? 1.0 : 0.0, mRx = i < NX - 1 ? 1.0 : 0.0, mLy = j > 0 ? 1.0 : 0.0, mRy = j < NY - 1 ? 1.0 : 0.0;
+  const double cMx = 2.0 * (mLx + mRx), cKx = mLx + mRx, cDx = mLx - mRx, cMy = 2.0 * (mLy + mRy), cKy = mLy + mRy, cDy = mLy - mRy;
+  const KronConsts &K = a.k;
+
+  auto load_plane = [&](int p, double (&v)[3], unsigned &m) {
+    v[0] = v[1] = v[2] = 0.0; m = 0;
+    if (p < 0 || p >= NZ || !vn) return;
+    const int64_t node = ((int64_t)p * NY + j) * NX + i;
+    v[0] = x[node * 3]; v[1] = x[node * 3 + 1]; v[2] = x[node * 3 + 2];
+    if (a.constrained && (a.mask_anywhere || p == 0 || p == NZ - 1 || bnd_xy)) m = a.nodemask[node];
+  };
+  auto apply_mask = [&](double (&v)[3], unsigned m) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) if (m & (1u << c)) v[c] = 0.0;
+  };
+  double W0[3], W1[3], W2[3];   // planes k-1, k, k+1
+  unsigned m0;
+  load_plane(k0 - 1, W0, m0); apply_mask(W0, m0); load_plane(k0, W1, m0); apply_mask(W1, m0); load_plane(k0 + 1, W2, m0); apply_mask(W2, m0);
+
+  const double *Lb = L;
+  double s1, d1, own;
+  auto nb = [&](int q) {
+    const double *col = Lb + (q * TYR + r) * TXN + lx;
+    const double nm1 = col[-TXN], np1 = col[TXN];
+    own = col[0]; s1 = nm1 + np1; d1 = nm1 - np1;
+  };
+  auto sweepM = [&]() { return fma(cMy, own, s1); };
+  auto sweepK = [&]() { return fma(cKy, own, -s1); };
+  auto sweepO = [&]() { return d1; };
+  int buf = 0;
+  double dot_acc = 0.0;
+
+  for (int kk = k0; kk < k1; ++kk) {
+    double *Lw = L + buf * (9 * TYR * TXN);
+    const double mL = kk > 0 ? 1.0 : 0.0, mR = kk < NZ - 1 ? 1.0 : 0.0;
+    {
+      const double cM = 2.0 * (mL + mR), cK = mL + mR;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double t1 = W0[c] + W2[c];
+        Lw[(c * TYR + r) * TXN + lx] = fma(cM, W1[c], t1);              // mz
+        Lw[((3 + c) * TYR + r) * TXN + lx] = fma(cK, W1[c], -t1);       // kz
+        Lw[((6 + c) * TYR + r) * TXN + lx] = W0[c] - W2[c];             // oz
+      }
+    }
+    const bool has_w = kk == 0 || kk == NZ - 1;
+    const double xc[3] = {W1[0], W1[1], W1[2]};   // this plane's (masked) input values
+    // plane k-1 is no longer needed: prefetch plane k+2 into its registers, rotate when the plane is done
+    unsigned mp; load_plane(kk + 2, W0, mp);
+    __syncthreads();
+    Lb = Lw; buf ^= 1;
+
+    auto xstage = [&](const double FK, const double FM, const double FO, const double FD) {
+      const double t1 = FM - FK;
+      return fma(cKx, FK, fma(cMx, FM, cDx * FD)) + wave_up1(t1 + FO) + wave_dn1(t1 - FO);   // from i-1 and i+1
+    };
+    const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
+    auto emit = [&](int c, double v) { if (out) { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); } };
+
+    if (!has_w) {
+      if (!halo_wave) {
+        double XK0, XM0, XO0, XD0, XK1, XM1, XO1, XD1;
+        { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;
+          XK0 = K.xk_l2g * My; XM0 = K.m_gKyMz * Ky; XO1 = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD1 = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
+        { nb(3); XM0 = fma(K.m_gMyKz, sweepM(), XM0); }
+        { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;
+          XK1 = K.xk_g * My; XM1 = K.m_lKyMz * Ky; XO0 = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD0 = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
+        { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;
+          XO0 = fma(K.cc_oz[0], My, XO0); XD0 = fma(K.cc_oz[2], My, XD0); XM1 = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM1)); }
+        emit(0, xstage(XK0, XM0, XO0, XD0));
+        { nb(4); XM1 = fma(K.m_gMyKz, sweepM(), XM1); }
+        emit(1, xstage(XK1, XM1, XO1, XD1));
+        double XK2, XM2, XO2, XD2;
+        { nb(2); const double My = sweepM(), Ky = sweepK(); XK2 = K.xk_g * My; XM2 = K.m_gKyMz * Ky; }
+        { nb(5); XM2 = fma(K.m_lMyKz, sweepM(), XM2); }
+        { nb(6); const double My = sweepM(); XO2 = K.cc_oz[0] * My; XD2 = K.cc_oz[1] * My; }
+        { nb(7); const double Oy = sweepO(), Dy = cDy * own; XM2 = fma(K.cc_mx[0], Oy, fma(K.cc_mx[1], Dy, XM2)); }
+        emit(2, xstage(XK2, XM2, XO2, XD2));
+      }
+    } else {   // first / last plane of the box: additionally the boundary diagonal D_z = mL - mR of C_z, through slots 0..2 in a second round
+      double XK[3], XM[3], XO[3], XD[3];
+      const double cD = mL - mR;
+      if (!halo_wave) {
+        { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;
+          XK[0] = K.xk_l2g * My; XM[0] = K.m_gKyMz * Ky; XO[1] = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD[1] = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
+        { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;
+          XK[1] = K.xk_g * My; XM[1] = K.m_lKyMz * Ky; XO[0] = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD[0] = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
+        { nb(2); const double My = sweepM(), Ky = sweepK(); XK[2] = K.xk_g * My; XM[2] = K.m_gKyMz * Ky; }
+        { nb(3); XM[0] = fma(K.m_gMyKz, sweepM(), XM[0]); }
+        { nb(4); XM[1] = fma(K.m_gMyKz, sweepM(), XM[1]); }
+        { nb(5); XM[2] = fma(K.m_lMyKz, sweepM(), XM[2]); }
+        { nb(6); const double My = sweepM(); XO[2] = K.cc_oz[0] * My; XD[2] = K.cc_oz[1] * My; }
+        { nb(7); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[1], Dy, XM[2])); }
+        { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;
+          XO[0] = fma(K.cc_oz[0], My, XO[0]); XD[0] = fma(K.cc_oz[2], My, XD[0]); XM[1] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM[1])); }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Lw[(c * TYR + r) * TXN + lx] = cD * xc[c];
+      __syncthreads();
+      if (!halo_wave) {
+        { nb(0); const double My = sweepM(); XO[2] = fma(K.cc_oz[2], My, XO[2]); XD[2] = fma(K.cc_oz[3], My, XD[2]); }
+        { nb(1); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[2], Oy, fma(K.cc_mx[3], Dy, XM[2])); }
+        { nb(2); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;
+          XO[0] = fma(K.cc_oz[1], My, XO[0]); XD[0] = fma(K.cc_oz[3], My, XD[0]); XM[1] = fma(K.cc_mx[1], Oy, fma(K.cc_mx[3], Dy, XM[1])); }
+      }
+      __syncthreads();
+      if (!halo_wave) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) emit(c, xstage(XK[c], XM[c], XO[c], XD[c]));
+      }
+    }
+    // rotate the window by one plane; the prefetched plane gets its Dirichlet columns zeroed as it enters
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const double t0 = W0[c]; W0[c] = W1[c]; W1[c] = W2[c]; W2[c] = t0; }
+    apply_mask(W2, mp);
+  }
+  if (a.dot_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_xor(dot_acc, off, 64);
+    __syncthreads();
+    if (lane == 0) L[w] = dot_acc;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int q = 0; q < 16; ++q) t += L[q]; a.dot_partials[blockIdx.x] = t; }
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+k_kron3_q1(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ double L[];
+  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
+  if (tile < a.nA) kron_tile_q1<64>(a, x, y, L, 62 * (tile / (a.nzc * a.nty64)) - 1, (tile / a.nzc) % a.nty64, tile % a.nzc);
+  else { const int t = tile - a.nA; kron_tile_q1<32>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+}
+
 // y_i = diag_i x_i on the Dirichlet rows (ConstraintMatrix elimination), from the constraint list
 __global__ void __launch_bounds__(256)
 k_kron_fix_constrained(int64_t n, const int32_t *__restrict__ dofs, const double *__restrict__ diag_local, const double *__restrict__ x, double *__restrict__ y,
@@ -304,20 +459,22 @@ void check_q2_element_matrices() {
 
 }  // namespace
 
-bool kron_supported(int dim, int k_u) { return dim == 3 && k_u == 2; }
+bool kron_supported(int dim, int k_u) { return dim == 3 && (k_u == 1 || k_u == 2); }
 
 int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials) {
   static bool checked = false;
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
-  for (int d = 0; d < 3; ++d) a.nn[d] = 2 * m.box.n[d] + 1;
-  // x-extent = full 60-wide tiles + (when what is left fits) one 28-wide tile column
-  a.n64 = a.nn[0] / 60; const int rem = a.nn[0] - 60 * a.n64;
+  const int ku = m.k_u;
+  for (int d = 0; d < 3; ++d) a.nn[d] = ku * m.box.n[d] + 1;
+  // tile shapes: (64 lanes x 16 rows) and (32 x 32); valid outputs 60 x 12 / 28 x 28 for Q2 (halo 2), 62 x 14 / 30 x 30 for Q1 (halo 1)
+  const int vx64 = ku == 2 ? 60 : 62, vx32 = ku == 2 ? 28 : 30, vy64 = ku == 2 ? 12 : 14, vy32 = ku == 2 ? 28 : 30, halo = ku == 2 ? 2 : 1;
+  // x-extent = full 64-lane tiles + (when what is left fits) one 32-lane tile column
+  a.n64 = a.nn[0] / vx64; const int rem = a.nn[0] - vx64 * a.n64;
   a.has32 = 0;
-  if (rem > 28) a.n64 += 1; else if (rem > 0) a.has32 = 1;
-  if (a.n64 == 0 && !a.has32) a.has32 = 1;
-  a.x0_32 = 60 * a.n64 - 2;
-  a.nty64 = (a.nn[1] + 11) / 12; a.nty32 = (a.nn[1] + 27) / 28;
+  if (rem > vx32) a.n64 += 1; else if (rem > 0) a.has32 = 1;
+  a.x0_32 = vx64 * a.n64 - halo;
+  a.nty64 = (a.nn[1] + vy64 - 1) / vy64; a.nty32 = (a.nn[1] + vy32 - 1) / vy32;
   // z-chunks: as many workgroups as fit the chip in ONE round (one 1024-thread workgroup per CU), an even number of planes each
   const int cols = a.n64 * a.nty64 + a.has32 * a.nty32;
   int nzc = n_cus / cols; if (nzc < 1) nzc = 1;
@@ -325,7 +482,8 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   a.chunk = chunk; a.nzc = (a.nn[2] + chunk - 1) / chunk;
   a.nA = a.n64 * a.nty64 * a.nzc; a.nblocks = a.nA + a.has32 * a.nty32 * a.nzc;
   const double lam = m.lam, G = m.G, l2g = lam + 2 * G, c[4] = {-(lam + G), lam - G, G - lam, lam + G};
-  const double sM[3] = {m.box.h[0] / 30, m.box.h[1] / 30, m.box.h[2] / 30}, sK[3] = {1 / (3 * m.box.h[0]), 1 / (3 * m.box.h[1]), 1 / (3 * m.box.h[2])}, sC = 1.0 / 6;
+  const double mdiv = ku == 2 ? 30.0 : 6.0, kmul = ku == 2 ? 1.0 / 3.0 : 1.0, sC = ku == 2 ? 1.0 / 6 : 0.5;   // scales of the integer 1D matrices
+  const double sM[3] = {m.box.h[0] / mdiv, m.box.h[1] / mdiv, m.box.h[2] / mdiv}, sK[3] = {kmul / m.box.h[0], kmul / m.box.h[1], kmul / m.box.h[2]};
   KronConsts &k = a.k;
   k.xk_l2g = l2g * sM[1] * sK[0] * sM[2]; k.xk_g = G * sM[1] * sK[0] * sM[2];
   k.m_gKyMz = G * sK[1] * sM[0] * sM[2]; k.m_gMyKz = G * sM[1] * sM[0] * sK[2]; k.m_lKyMz = l2g * sK[1] * sM[0] * sM[2]; k.m_lMyKz = l2g * sM[1] * sM[0] * sK[2];
@@ -333,11 +491,16 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   a.nodemask = m.nodemask; a.constrained = constrained ? 1 : 0; a.mask_anywhere = m.mask_anywhere;
   const size_t lds = (size_t)NFLD * kTileNodes * sizeof(double);
   static bool attr_set = false;
-  if (!attr_set) { PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+  if (!attr_set) {
+    PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   const int nblk = a.nblocks;
   if (dot_partials && nblk > kMaxPartials / 2) throw Error("kron_apply: too many workgroups for the fused dot product");
   a.dot_partials = dot_partials;
-  hipLaunchKernelGGL(k_kron3_q2, (unsigned)nblk, 1024, lds, s, a, x, y);
+  if (ku == 2) hipLaunchKernelGGL(k_kron3_q2, (unsigned)nblk, 1024, lds, s, a, x, y);
+  else hipLaunchKernelGGL(k_kron3_q1, (unsigned)nblk, 1024, lds, s, a, x, y);
   return nblk;
 }
 

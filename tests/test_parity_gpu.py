@@ -215,11 +215,12 @@ def test_error_behaviour():
     Pm.close()
 
 
-@pytest.mark.parametrize("n", [(3, 3, 3), (31, 7, 9), (5, 40, 3), (64, 13, 40), (30, 6, 1), (33, 12, 24)], ids=str)
-def test_sum_factorised_operator_equals_element_matrix_operator(n, monkeypatch):
-    """k_kron3_q2 (Kronecker sweeps) vs k_mf_apply (element-matrix gather, itself checked against the oracle's CSR above) on boxes
-    spanning several x / y tiles and z chunks, with and without Dirichlet rows; 1e-12 relative to the result's max."""
-    P = box_problem(3, n, 2)
+@pytest.mark.parametrize("deg", [2, 1])
+@pytest.mark.parametrize("n", [(3, 3, 3), (31, 7, 9), (5, 40, 3), (64, 13, 40), (30, 6, 1), (33, 12, 24), (70, 31, 5), (91, 17, 33)], ids=str)
+def test_sum_factorised_operator_equals_element_matrix_operator(n, deg, monkeypatch):
+    """k_kron3_q2 / k_kron3_q1 (Kronecker sweeps) vs k_mf_apply (element-matrix gather, itself checked against the oracle's CSR above) on
+    boxes spanning several x / y tiles of both shapes and z chunks, with and without Dirichlet rows; 1e-12 relative to the result's max."""
+    P = box_problem(3, n, deg)
     x = synth(P.desc.n_dofs_u, 0.11) + 0.3
     ys = []
     for variant in ("kron", "gather"):
