@@ -170,8 +170,12 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     # tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py); null when no profile is committed
+    kron = dim == 3
+    kernel_label = ("k_kron3_q%d (matrix-free y = A_u x, sum-factorised)" % deg) if kron else ("k_mf_apply<%d,%d> (matrix-free y = A_u x, element-matrix gather)" % (dim, deg))
     traffic = None
     try:
+        if not (dim == 3 and deg == 2 and args.n == 72):
+            raise KeyError("profile is for the default workload only")
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_kron_v3.json")) as f:
             traffic = json.load(f)["poro::k_kron3_q2"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
@@ -186,10 +190,11 @@ def main():
                                    f"(pressure loop + matrix-free Jacobi-PCG displacement solve + strain projection); input.data material/BCs, z-face BCs per SURVEY Q9",
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU", "operator": "matrix_free",
                        "stopping_rule_u": f"recursive residual <= max(1e-12, {args.rel_tol:g}*||b||), cap {args.max_iter}"},
-            "roofline": {"bound": "hbm", "kernel": "k_kron3_q2 (matrix-free y = A_u x, sum-factorised)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e6 * avg_apply, "launches_timed": n_apply,
-                         "note": "k_kron3_q2 alone (as rocprofv3 reports it); the Dirichlet rows are finished by the list kernel k_kron_fix_constrained, avg %.1f us per operator application" % (1e6 * t_fix / max(n_fix, 1))},
+                         "note": ("operator kernel alone (as rocprofv3 reports it); the Dirichlet rows are finished by the list kernel k_kron_fix_constrained, avg %.1f us per operator application; "
+                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells) although the structured kernels read no index arrays") % (1e6 * t_fix / max(n_fix, 1))},
             "work_per_step": {k: work[k] / args.steps for k in work},
             "kernel_only": {"apply_u_DoF_updates_per_s": (P.desc.n_dofs_u / (avg_apply + t_fix / max(n_fix, 1))) if n_apply else 0.0,
                             "seconds_by_family": {k: v[0] for k, v in kernel_time.items()}, "launches_by_family": {k: v[1] for k, v in kernel_time.items()}},
