@@ -133,9 +133,12 @@ typedef struct poro_solver_opts {
   double  rel_tol;
   int32_t max_iter;
   int32_t preconditioner;  /* PORO_PREC_* */
+  double  omega;           /* relaxation of PORO_PREC_SSOR: 1.2 displacement (:303), 1.0 pressure / projection (:178, StrainProjector.h:212) */
 } poro_solver_opts;
 
-enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1 };
+/* PORO_PREC_SSOR = PreconditionSSOR in the matrix's natural row order (level-scheduled sweeps; assembled-CSR operators only):
+ * reproduces the reference's Krylov iterates, at many small launches per application - a fidelity mode, not the fast path. */
+enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2 };
 enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };
 enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_JACOBIAN_P = 3 };
 enum { PORO_VEC_U = 0, PORO_VEC_RHS_U = 1, PORO_VEC_P = 2, PORO_VEC_P_OLD = 3, PORO_VEC_DP = 4,

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 # ids of include/poroel_hip.h
-PREC_NONE, PREC_JACOBI = 0, 1
+PREC_NONE, PREC_JACOBI, PREC_SSOR = 0, 1, 2
 OP_CSR, OP_MATRIX_FREE = 0, 1
 MAT_A_U, MAT_MASS_P, MAT_LAPLACE_P, MAT_JACOBIAN_P = 0, 1, 2, 3
 VEC_U, VEC_RHS_U, VEC_P, VEC_P_OLD, VEC_DP, VEC_RESIDUAL_P, VEC_EPSV, VEC_EPSV0, VEC_SOURCE_P = range(9)
@@ -53,7 +53,7 @@ class Desc(C.Structure):
 
 
 class SolverOpts(C.Structure):
-    _fields_ = [("abs_tol", C.c_double), ("rel_tol", C.c_double), ("max_iter", C.c_int32), ("preconditioner", C.c_int32)]
+    _fields_ = [("abs_tol", C.c_double), ("rel_tol", C.c_double), ("max_iter", C.c_int32), ("preconditioner", C.c_int32), ("omega", C.c_double)]
 
 
 class SolveInfo(C.Structure):
@@ -152,9 +152,9 @@ def load_host():
         L.poro_host_free.restype = None
         L.poro_host_read_input.argtypes = [C.c_char_p, C.POINTER(InputFlat)]
         L.poro_host_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
-                                    C.c_double, C.c_double, C.c_int, _dp, C.c_int, C.POINTER(C.c_void_p)]
+                                    C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_int, C.POINTER(C.c_void_p)]
         L.poro_host_runner_create.restype = C.c_void_p
-        L.poro_host_runner_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.poro_host_runner_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
         L.poro_host_runner_ctx.restype = C.c_void_p
         L.poro_host_runner_ctx.argtypes = [C.c_void_p]
         L.poro_host_runner_initialize.argtypes = [C.c_void_p]
@@ -279,12 +279,12 @@ class Context:
         self._chk(self.L.poro_disp_assemble_system(self.ptr, int(rebuild)))
 
     @staticmethod
-    def _opts(abs_tol, rel_tol, max_iter, prec):
-        return SolverOpts(abs_tol, rel_tol, max_iter, prec)
+    def _opts(abs_tol, rel_tol, max_iter, prec, omega=1.0):
+        return SolverOpts(abs_tol, rel_tol, max_iter, prec, omega)
 
-    def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_JACOBI):
+    def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_JACOBI, omega=1.2):
         info = SolveInfo()
-        rc = self._chk(self.L.poro_disp_solve(self.ptr, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec)), C.byref(info)))
+        rc = self._chk(self.L.poro_disp_solve(self.ptr, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega)), C.byref(info)))
         return rc, info
 
     def pres_assemble_residual(self, dt):
@@ -295,9 +295,9 @@ class Context:
     def pres_assemble_jacobian(self, dt):
         self._chk(self.L.poro_pres_assemble_jacobian(self.ptr, dt))
 
-    def pres_solve(self, abs_tol=0.0, rel_tol=1e-8, max_iter=1000, prec=PREC_JACOBI):
+    def pres_solve(self, abs_tol=0.0, rel_tol=1e-8, max_iter=1000, prec=PREC_JACOBI, omega=1.0):
         info = SolveInfo()
-        rc = self._chk(self.L.poro_pres_solve(self.ptr, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec)), C.byref(info)))
+        rc = self._chk(self.L.poro_pres_solve(self.ptr, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega)), C.byref(info)))
         return rc, info
 
     def pres_update_volumetric_strain(self):
@@ -310,9 +310,9 @@ class Context:
         a, p = _arr_i(comps)
         self._chk(self.L.poro_proj_assemble_rhs(self.ptr, p, a.size))
 
-    def proj_solve(self, entry, abs_tol=0.0, rel_tol=1e-8, max_iter=1000, prec=PREC_JACOBI):
+    def proj_solve(self, entry, abs_tol=0.0, rel_tol=1e-8, max_iter=1000, prec=PREC_JACOBI, omega=1.0):
         info = SolveInfo()
-        rc = self._chk(self.L.poro_proj_solve(self.ptr, entry, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec)), C.byref(info)))
+        rc = self._chk(self.L.poro_proj_solve(self.ptr, entry, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega)), C.byref(info)))
         return rc, info
 
     def get_volumetric_strain(self):
@@ -371,13 +371,13 @@ def rccl_unique_id():
 
 
 def run_problem(problem, n_steps, p_init, dt, device=0, operator_mode=OP_CSR, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
-                abs_u=1e-12, rel_u=0.0, max_it=1000):
+                abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI):
     """PoroElasticProblem<dim>::run() (PoroelasticityFSS.h:294-415) through the C++ host driver; returns (trace, Context)."""
     H = load_host()
     max_rows = 1 + n_steps * max_fss
     trace = np.zeros((max_rows, 8))
     ctx = C.c_void_p()
-    rows = H.poro_host_run(problem.handle, device, operator_mode, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it,
+    rows = H.poro_host_run(problem.handle, device, operator_mode, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec,
                            trace.ctypes.data_as(_dp), max_rows, C.byref(ctx))
     if rows < 0:
         raise RuntimeError(H.poro_host_last_error().decode())
@@ -391,10 +391,10 @@ class Runner:
     """Steppable PoroElasticProblem<dim> (C++ host driver): initialize() = PoroelasticityFSS.h:308-317, step() = one pass of :328-407."""
 
     def __init__(self, problem, device=0, operator_mode=OP_MATRIX_FREE, p_init=10e6, dt=60.0, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
-                 abs_u=1e-12, rel_u=0.0, max_it=1000):
+                 abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI):
         self.H = load_host()
         self.max_fss = max_fss
-        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it)
+        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec)
         if not h:
             raise RuntimeError(self.H.poro_host_last_error().decode())
         self.h = C.c_void_p(h)

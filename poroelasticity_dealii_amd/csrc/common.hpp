@@ -51,10 +51,13 @@ struct FeTablesDev {   // device copies of poro_fe_tables
   const double *w_qu, *w_qp, *w_qf, *u_qu, *du_qu, *du_qp, *q1_qu, *dq1_qu, *q1_qp, *dq1_qp, *u_qf, *dq1_qf;
 };
 
+// dependency levels of the lower / upper triangle in natural row order (rows of one level can be swept concurrently)
+struct SsorLevels { DevBuf<int32_t> fwd_rows, bwd_rows; std::vector<int64_t> fwd_off, bwd_off; bool built = false; };
 struct CsrDev {
   int64_t n = 0, nnz = 0;
   DevBuf<int64_t> rp; DevBuf<int32_t> col; DevBuf<int64_t> diag_pos;
   int lanes_per_row = 8;
+  SsorLevels ssor;
 };
 
 struct Timer { double seconds = 0; int64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
@@ -129,6 +132,8 @@ void la_pressure_tmp(hipStream_t s, double *t, const double *ev, const double *e
 void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, double a, double kappa, int64_t nnz);
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag);
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n);
+void la_xpby(hipStream_t s, double *y, double a, double b, const double *x, int64_t n);   // y = a y + b x
+void la_ssor_apply(hipStream_t s, const CsrDev &A, const double *val, const SsorLevels &lv, double omega, const double *src, double *dst);
 void la_sum_strains(hipStream_t s, double *ev, const double *const *strains, int n, int64_t len);
 void la_set_constrained(hipStream_t s, double *x, const uint8_t *mask, const double *val, int64_t n);
 void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const double *neumann, const uint8_t *mask, int64_t n);

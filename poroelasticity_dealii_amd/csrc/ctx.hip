@@ -266,6 +266,65 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   return hs.converged ? 0 : 1;
 }
 
+// ---- PreconditionSSOR fidelity mode: SolverCG with the reference's SSOR(omega) in natural row order ---------------------------
+void build_ssor_levels(poro_ctx *c, CsrDev &A) {
+  if (A.ssor.built) return;
+  std::vector<int64_t> rp(A.n + 1); std::vector<int32_t> col(A.nnz);
+  PORO_HIP(hipMemcpy(rp.data(), A.rp.p, (A.n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost)); PORO_HIP(hipMemcpy(col.data(), A.col.p, A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  auto levels = [&](bool fwd, DevBuf<int32_t> &rows_dev, std::vector<int64_t> &off) {
+    std::vector<int32_t> lvl(A.n, 0); int maxl = 0;
+    if (fwd) for (int64_t r = 0; r < A.n; ++r) { int l = 0; for (int64_t j = rp[r]; j < rp[r + 1] && col[j] < r; ++j) l = std::max(l, lvl[col[j]] + 1); lvl[r] = l; maxl = std::max(maxl, l); }
+    else for (int64_t r = A.n - 1; r >= 0; --r) { int l = 0; for (int64_t j = rp[r + 1] - 1; j >= rp[r] && col[j] > r; --j) l = std::max(l, lvl[col[j]] + 1); lvl[r] = l; maxl = std::max(maxl, l); }
+    off.assign(maxl + 2, 0);
+    for (int64_t r = 0; r < A.n; ++r) off[lvl[r] + 1]++;
+    for (int l = 0; l <= maxl; ++l) off[l + 1] += off[l];
+    std::vector<int32_t> rows(A.n); std::vector<int64_t> pos(off.begin(), off.end() - 1);
+    for (int64_t r = 0; r < A.n; ++r) rows[pos[lvl[r]]++] = (int32_t)r;
+    rows_dev.upload(rows);
+  };
+  levels(true, A.ssor.fwd_rows, A.ssor.fwd_off); levels(false, A.ssor.bwd_rows, A.ssor.bwd_off);
+  A.ssor.built = true;
+}
+double dot_host(poro_ctx *c, const double *a, const double *b, int64_t n) {
+  la_dot_partials(c->stream, a, b, n, c->partials.p); la_reduce_finish(c->stream, c->partials.p, 1, c->red.p, 0);
+  double h; PORO_HIP(hipMemcpyAsync(&h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+  return h;
+}
+// SolverCG<>::solve with PreconditionSSOR, host-driven scalars (fidelity mode: many small launches per application)
+int pcg_ssor(poro_ctx *c, CsrDev &A, const double *val, double *x, const double *b, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
+  if (c->comm.multi()) throw Error("PORO_PREC_SSOR is a single-rank fidelity mode (the sweeps are order dependent)");
+  build_ssor_levels(c, A);
+  hipStream_t s = c->stream; const int64_t n = A.n; const double om = opts->omega > 0 ? opts->omega : 1.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  const double tol = std::max(opts->abs_tol, opts->rel_tol * std::sqrt(dot_host(c, b, b, n)));
+  int64_t applies = 0; int it = 0, conv = 0;
+  la_csr_spmv(s, A, val, x, g); ++applies;
+  la_axpy(s, g, -1.0, b, n);                                     // g = A x - b
+  double res = std::sqrt(dot_host(c, g, g, n)); const double res0 = res;
+  if (res <= tol) conv = 1;
+  else {
+    la_ssor_apply(s, A, val, A.ssor, om, g, h);
+    la_fill(s, d, 0.0, n); la_axpy(s, d, -1.0, h, n);          // d = -h
+    double gh = dot_host(c, g, h, n);
+    while (true) {
+      ++it;
+      la_csr_spmv(s, A, val, d, h); ++applies;
+      const double alpha = gh / dot_host(c, d, h, n);
+      la_axpy(s, g, alpha, h, n); la_axpy(s, x, alpha, d, n);
+      res = std::sqrt(dot_host(c, g, g, n));
+      if (res <= tol) { conv = 1; break; }
+      if (it >= opts->max_iter) break;
+      la_ssor_apply(s, A, val, A.ssor, om, g, h);
+      const double beta_old = gh; gh = dot_host(c, g, h, n);
+      la_xpby(s, d, gh / beta_old, -1.0, h, n);                   // d = beta d - h
+    }
+  }
+  PORO_HIP(hipStreamSynchronize(s));
+  if (info) { info->iterations = it; info->converged = conv; info->initial_residual = res0; info->final_residual = res; info->operator_applications = applies;
+              info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  return conv ? 0 : 1;
+}
+
 void setup(poro_ctx *c, const poro_desc *d) {
   if (d->abi_version != PORO_ABI_VERSION) throw Error("poro_desc.abi_version mismatch");
   if (d->dim != 2 && d->dim != 3) throw Error("dim must be 2 or 3");
@@ -536,6 +595,13 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     PORO_HIP(hipSetDevice(c->device));
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
+    if (opts->preconditioner == PORO_PREC_SSOR) {
+      if (mode != PORO_OP_CSR) throw Error("PORO_PREC_SSOR needs the assembled CSR operator");
+      const int rc = pcg_ssor(c, c->Au, c->Au_val.p, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
+      la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
+      PORO_HIP(hipStreamSynchronize(c->stream));
+      return rc;
+    }
     auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp); };
     DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim;
     if (c->diag_u_cls.p) { dv.cls = c->diag_u_cls.p; dv.tab = c->diag_u_tab.p; }
@@ -583,6 +649,7 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (c->jac_dt < 0) throw Error("pres_solve before pres_assemble_jacobian");
+    if (opts->preconditioner == PORO_PREC_SSOR) return pcg_ssor(c, c->Ap, c->Jp.p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;   // uniform box: J is a constant-coefficient stencil
     const double ja = 1. / c->mat.biot_M / c->jac_dt, jk = c->mat.k_over_mu;
     auto apply = [&](const double *x, double *y, double *) {
@@ -637,6 +704,7 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
     PORO_HIP(hipSetDevice(c->device));
     if (!c->projection_matrix_ready) throw Error("proj_solve before proj_assemble_matrix");
     if (entry < 0 || entry >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
+    if (opts->preconditioner == PORO_PREC_SSOR) return pcg_ssor(c, c->Ap, c->Mp.p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;
     auto apply = [&](const double *x, double *y, double *) {
       if (stencil) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(c->stream, c->dim, c->box, 1.0, 0.0, x, y); }

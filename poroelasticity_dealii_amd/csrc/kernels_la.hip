@@ -150,6 +150,33 @@ __global__ void k_rhs_u_finish(double *rhs, const double *lift, const double *ne
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) rhs[i] = mask[i] ? 0.0 : (rhs[i] + neu[i]) + lift[i];
 }
 
+// ---- SparseMatrix::precondition_SSOR in natural row order, level-scheduled: dst = (D + wU)^-1 w(2-w) D (D + wL)^-1 src ------
+// one thread per row of the current dependency level; the in-row sum runs in ascending column order like the reference's loop
+__global__ void k_ssor_fwd(int64_t n_lvl, const int32_t *__restrict__ rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                           const double *__restrict__ val, const int64_t *__restrict__ dpos, double om, const double *__restrict__ src, double *dst) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_lvl) return;
+  const int32_t r = rows[t];
+  double s = 0;
+  for (int64_t j = rp[r]; j < dpos[r]; ++j) s += val[j] * dst[col[j]];
+  dst[r] = (src[r] - s * om) / val[dpos[r]];
+}
+__global__ void k_ssor_mid(int64_t n, const double *__restrict__ val, const int64_t *__restrict__ dpos, double om, double *dst) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) dst[i] *= om * (2. - om) * val[dpos[i]];
+}
+__global__ void k_ssor_bwd(int64_t n_lvl, const int32_t *__restrict__ rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                           const double *__restrict__ val, const int64_t *__restrict__ dpos, double om, double *dst) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_lvl) return;
+  const int32_t r = rows[t];
+  double s = 0;
+  for (int64_t j = dpos[r] + 1; j < rp[r + 1]; ++j) s += val[j] * dst[col[j]];
+  dst[r] = (dst[r] - s * om) / val[dpos[r]];
+}
+__global__ void k_xpby(double *y, double a, double b, const double *x, int64_t n) {   // y = a y + b x
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] = a * y[i] + b * x[i];
+}
+
 // ---- PCG (deal.II SolverCG structure: g = A x - b, d = -P^-1 g) ----------------------------------
 // INVERSE Jacobi diagonal (z = g * dinv: no fp64 division in the streaming kernels) either as a full vector or
 // dictionary-compressed: class byte per node (ncomp dofs each) + table[class][comp]
@@ -318,6 +345,18 @@ void la_pressure_tmp(hipStream_t s, double *t, const double *ev, const double *e
 }
 void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, double a, double kappa, int64_t nnz) {
   hipLaunchKernelGGL(k_jacobian, grid_for(nnz), kBlock, 0, s, J, M, K, a, kappa, nnz);
+}
+void la_xpby(hipStream_t s, double *y, double a, double b, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_xpby, grid_for(n), kBlock, 0, s, y, a, b, x, n); }
+void la_ssor_apply(hipStream_t s, const CsrDev &A, const double *val, const SsorLevels &lv, double omega, const double *src, double *dst) {
+  for (size_t l = 0; l + 1 < lv.fwd_off.size(); ++l) {
+    const int64_t n = lv.fwd_off[l + 1] - lv.fwd_off[l];
+    hipLaunchKernelGGL(k_ssor_fwd, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, s, n, lv.fwd_rows.p + lv.fwd_off[l], A.rp.p, A.col.p, val, A.diag_pos.p, omega, src, dst);
+  }
+  hipLaunchKernelGGL(k_ssor_mid, grid_for(A.n), kBlock, 0, s, A.n, val, A.diag_pos.p, omega, dst);
+  for (size_t l = 0; l + 1 < lv.bwd_off.size(); ++l) {
+    const int64_t n = lv.bwd_off[l + 1] - lv.bwd_off[l];
+    hipLaunchKernelGGL(k_ssor_bwd, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, s, n, lv.bwd_rows.p + lv.bwd_off[l], A.rp.p, A.col.p, val, A.diag_pos.p, omega, dst);
+  }
 }
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_reciprocal, grid_for(n), kBlock, 0, s, y, x, n); }
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag) {

@@ -40,6 +40,7 @@ struct RunControls {
   double p_init = 10e6, time_step = 60; int n_steps = 1;
   double fss_tol = 1e-8, pressure_tol = 1e-8; int max_fss_iterations = 50, max_pressure_iterations = 50;
   double abs_tol_u = 1e-12, rel_tol_u = 0.0; int max_iter = 1000;   // PoroElasticDisplacementSolver.h:298-299
+  int preconditioner = PORO_PREC_JACOBI;                            // PORO_PREC_SSOR = the reference's PreconditionSSOR (CSR operator, one rank)
 };
 
 }  // namespace poro_host
@@ -50,7 +51,7 @@ using poro_host::DeviceVector;
 template <int dim> class PoroElasticDisplacementSolver {
  public:
   DeviceVector solution;                                   // PoroElasticDisplacementSolver.h:47
-  poro_solver_opts control{1e-12, 0.0, 1000, PORO_PREC_JACOBI};   // :298-299 (SSOR(1.2) -> Jacobi on device)
+  poro_solver_opts control{1e-12, 0.0, 1000, PORO_PREC_JACOBI, 1.2};   // :298-299, omega :303 (Jacobi is the fast default; PORO_PREC_SSOR = the reference's)
   poro_solve_info  last{};
   explicit PoroElasticDisplacementSolver(poro_ctx *c) : ctx(c) { solution.ctx = c; solution.id = PORO_VEC_U; }
   void setup_dofs() { rebuild_system_matrix = true; }      // :106-153 (pattern / constraints are built by poro_ctx_create)
@@ -72,7 +73,7 @@ template <int dim> class PoroElasticDisplacementSolver {
 template <int dim> class PoroElasticPressureSolver {
  public:
   DeviceVector solution, solution_update, old_solution, residual;   // PoroElasticPressureSolver.h:38-40
-  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI};       // :175
+  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI, 1.0};       // :175, omega :178
   poro_solve_info  last{};
   explicit PoroElasticPressureSolver(poro_ctx *c) : ctx(c) {
     solution.ctx = solution_update.ctx = old_solution.ctx = residual.ctx = c;
@@ -103,7 +104,7 @@ template <int dim> class PoroElasticPressureSolver {
 namespace projection {
 template <int dim> class StrainProjector {
  public:
-  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI};       // StrainProjector.h:209
+  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI, 1.0};       // StrainProjector.h:209, omega :212
   poro_solve_info  last{};
   StrainProjector() {}
   void set_solvers(poro_ctx *c) { ctx = c; }               // :73-79
@@ -177,6 +178,7 @@ template <int dim> class PoroElasticProblem {
   void initialize(const RunControls &rc) {
     displacement_solver.control.abs_tol = rc.abs_tol_u; displacement_solver.control.rel_tol = rc.rel_tol_u;
     displacement_solver.control.max_iter = pressure_solver.control.max_iter = strain_projector.control.max_iter = rc.max_iter;
+    displacement_solver.control.preconditioner = pressure_solver.control.preconditioner = strain_projector.control.preconditioner = rc.preconditioner;
     setup_dofs();                                          // :308
     pressure_solver.solution = rc.p_init;                  // :311
     assemble_displacement();                               // :312

@@ -111,6 +111,46 @@ def test_displacement_solve_and_projection(pair, mode):
         G.close()
 
 
+def test_ssor_cg_follows_the_reference_iteration(pair):
+    """PORO_PREC_SSOR = PreconditionSSOR(omega) in natural row order (PoroElasticDisplacementSolver.h:300-307,
+    PoroElasticPressureSolver.h:176-181, StrainProjector.h:210-215): the same Krylov sequence as the oracle's SSOR-CG,
+    so the iteration counts agree, not only the converged fields."""
+    P, O, G = pair
+    p = 10e6 * (1 + 0.1 * synth(G.n_p))
+    O.set(pk.VEC_P, p); G.set(pk.VEC_P, p)
+    O.disp_assemble_system(True); G.disp_assemble_system(True)
+    rc0, i0 = O.disp_solve(abs_tol=1e-12, max_iter=1000, omega=1.2)
+    rc, i1 = G.disp_solve(abs_tol=1e-12, max_iter=1000, prec=pk.PREC_SSOR, omega=1.2)
+    assert rc0 == 0 and rc == 0
+    assert abs(i1.iterations - i0.iterations) <= 2, (i1.iterations, i0.iterations)
+    assert abs(i1.initial_residual - i0.initial_residual) <= 1e-10 * i0.initial_residual
+    assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-9
+    # capped solve: after the same k iterations both sit on the same iterate (the sweeps are order dependent, so this pins the order)
+    for S in (O, G):
+        S.fill(pk.VEC_U, 0.0)
+    k = max(3, i0.iterations // 3)
+    rc0, j0 = O.disp_solve(abs_tol=1e-300, max_iter=k, omega=1.2)
+    rc, j1 = G.disp_solve(abs_tol=1e-300, max_iter=k, prec=pk.PREC_SSOR, omega=1.2)
+    assert rc0 == 1 and rc == 1 and j0.iterations == k and j1.iterations == k
+    assert abs(j1.final_residual - j0.final_residual) <= 1e-6 * j0.final_residual
+    # pressure Jacobian and projection mass matrix, omega = 1
+    n = G.n_p
+    for key, v in {pk.VEC_P_OLD: p * 0.99, pk.VEC_EPSV: -2e-6 * (1 + 0.3 * synth(n, 0.5)), pk.VEC_EPSV0: -2e-6 * np.ones(n)}.items():
+        O.set(key, v); G.set(key, v)
+    O.pres_assemble_residual(60.0); G.pres_assemble_residual(60.0)
+    O.pres_assemble_jacobian(60.0); G.pres_assemble_jacobian(60.0)
+    rc0, i0 = O.pres_solve(rel_tol=1e-8); rc, i1 = G.pres_solve(rel_tol=1e-8, prec=pk.PREC_SSOR)
+    assert rc0 == 0 and rc == 0 and abs(i1.iterations - i0.iterations) <= 1, (i1.iterations, i0.iterations)
+    assert rel2(G.get(pk.VEC_DP), O.get(pk.VEC_DP)) <= 1e-7
+    F = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    try:
+        F.set(pk.VEC_P, p); F.disp_assemble_system(True)
+        with pytest.raises(RuntimeError, match="CSR"):
+            F.disp_solve(prec=pk.PREC_SSOR)
+    finally:
+        F.close()
+
+
 def test_pressure_residual_jacobian_solve(pair):
     P, O, G = pair
     n = G.n_p
@@ -172,6 +212,27 @@ def test_run_trace_matches_oracle(cfg):
             # eps_v comes from projections both sides stop at the reference's 1e-8*||rhs|| (StrainProjector.h:209) with
             # different preconditioners, so they agree to ~cond(M)*1e-8, not to solver-independent precision
             assert rel2(G.get(pk.VEC_EPSV), O.get(pk.VEC_EPSV)) <= 1e-6
+        finally:
+            G.close()
+    finally:
+        O.close(); P.close()
+
+
+def test_run_with_reference_preconditioner_reproduces_cg_counts():
+    """The whole run() with PORO_PREC_SSOR (the reference's SolverCG + PreconditionSSOR): CG iteration counts of the
+    displacement and pressure solves follow the oracle's SSOR-CG step by step, and eps_v agrees beyond solver tolerance
+    because both sides now stop on the same iterate."""
+    P = box_problem(2, 16, 2, mat=host_material())
+    O = oracle_py.Oracle(P)
+    try:
+        t0, _ = O.run(2, REF["p_init"], REF["dt"], max_it=1000)
+        t1, G = pk.run_problem(P, 2, REF["p_init"], REF["dt"], operator_mode=pk.OP_CSR, max_it=1000, prec=pk.PREC_SSOR)
+        try:
+            assert t1.shape == t0.shape and np.array_equal(t1[:, :3], t0[:, :3])
+            assert np.abs(t1[:, 6] - t0[:, 6]).max() <= 2, (t1[:, 6], t0[:, 6])     # displacement CG iterations
+            assert np.abs(t1[:, 7] - t0[:, 7]).max() <= 1, (t1[:, 7], t0[:, 7])     # pressure CG iterations
+            assert rel2(G.get(pk.VEC_P), O.get(pk.VEC_P)) <= 1e-10
+            assert rel2(G.get(pk.VEC_EPSV), O.get(pk.VEC_EPSV)) <= 1e-9
         finally:
             G.close()
     finally:
