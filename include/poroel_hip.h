@@ -137,8 +137,11 @@ typedef struct poro_solver_opts {
 } poro_solver_opts;
 
 /* PORO_PREC_SSOR = PreconditionSSOR in the matrix's natural row order (level-scheduled sweeps; assembled-CSR operators only):
- * reproduces the reference's Krylov iterates, at many small launches per application - a fidelity mode, not the fast path. */
-enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2 };
+ * reproduces the reference's Krylov iterates, at many small launches per application - a fidelity mode, not the fast path.
+ * PORO_PREC_FDM = fast diagonalisation: on a uniform box (poro_desc.box.enabled, one rank) the pressure Jacobian and the projection
+ * mass matrix are sums of Kronecker products of 1D matrices and are inverted exactly by 2*dim batched dense transforms (fp64 MFMA);
+ * CG keeps the reference's stopping rule and needs 1-2 iterations.  poro_supports_preconditioner() tells whether a context can. */
+enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3 };
 enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };
 enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_JACOBIAN_P = 3 };
 enum { PORO_VEC_U = 0, PORO_VEC_RHS_U = 1, PORO_VEC_P = 2, PORO_VEC_P_OLD = 3, PORO_VEC_DP = 4,
@@ -189,6 +192,8 @@ int  poro_vec_norm(poro_ctx *ctx, int which, double *l2, double *linf);
 int  poro_disp_assemble_system(poro_ctx *ctx, int rebuild_matrix);
 /* PoroElasticDisplacementSolver<dim>::solve (:294-307): PCG, warm start from PORO_VEC_U, then constraints.distribute. */
 int  poro_disp_solve(poro_ctx *ctx, const poro_solver_opts *opts, poro_solve_info *info);
+/* 1 if `preconditioner` can be used by poro_pres_solve / poro_proj_solve (which_system = 1) or poro_disp_solve (which_system = 0) on this context, else 0 */
+int  poro_supports_preconditioner(poro_ctx *ctx, int32_t which_system, int32_t preconditioner);
 
 /* PoroElasticPressureSolver<dim>::assemble_residual (:113-155) from PORO_VEC_{P,P_OLD,EPSV,EPSV0}; l2 = residual.l2_norm() (PoroelasticityFSS.h:364) */
 int  poro_pres_assemble_residual(poro_ctx *ctx, double time_step, double *l2);

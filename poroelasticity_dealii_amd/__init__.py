@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 # ids of include/poroel_hip.h
-PREC_NONE, PREC_JACOBI, PREC_SSOR = 0, 1, 2
+PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM = 0, 1, 2, 3
 OP_CSR, OP_MATRIX_FREE = 0, 1
 MAT_A_U, MAT_MASS_P, MAT_LAPLACE_P, MAT_JACOBIAN_P = 0, 1, 2, 3
 VEC_U, VEC_RHS_U, VEC_P, VEC_P_OLD, VEC_DP, VEC_RESIDUAL_P, VEC_EPSV, VEC_EPSV0, VEC_SOURCE_P = range(9)
@@ -81,7 +81,7 @@ SENDRECV_FN = C.CFUNCTYPE(None, _dp, _dp, C.c_int64, C.c_int32, C.c_void_p)
 HIP_SYMBOLS = [
     "poro_last_error", "poro_abi_version", "poro_ctx_create", "poro_ctx_destroy", "poro_comm_unique_id", "poro_ctx_comm_init_rccl",
     "poro_ctx_comm_init_callbacks", "poro_vec_set", "poro_vec_get", "poro_vec_fill", "poro_vec_copy", "poro_vec_axpy", "poro_vec_norm",
-    "poro_disp_assemble_system", "poro_disp_solve", "poro_pres_assemble_residual", "poro_pres_assemble_jacobian", "poro_pres_solve",
+    "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_assemble_jacobian", "poro_pres_solve",
     "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain",
     "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_bench_operator", "poro_timers_reset", "poro_timers_enable", "poro_timers_get"]
 
@@ -115,6 +115,7 @@ def load_hip():
         L.poro_vec_norm.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.poro_disp_assemble_system.argtypes = [C.c_void_p, C.c_int]
         L.poro_disp_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]
+        L.poro_supports_preconditioner.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.poro_pres_assemble_residual.argtypes = [C.c_void_p, C.c_double, _dp]
         L.poro_pres_assemble_jacobian.argtypes = [C.c_void_p, C.c_double]
         L.poro_pres_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]
@@ -281,6 +282,10 @@ class Context:
     @staticmethod
     def _opts(abs_tol, rel_tol, max_iter, prec, omega=1.0):
         return SolverOpts(abs_tol, rel_tol, max_iter, prec, omega)
+
+    def supports_preconditioner(self, which_system, prec):
+        """which_system: 0 displacement, 1 pressure / projection."""
+        return bool(self.L.poro_supports_preconditioner(self.ptr, which_system, prec))
 
     def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_JACOBI, omega=1.2):
         info = SolveInfo()

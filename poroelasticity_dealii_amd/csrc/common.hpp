@@ -51,6 +51,11 @@ struct FeTablesDev {   // device copies of poro_fe_tables
   const double *w_qu, *w_qp, *w_qf, *u_qu, *du_qu, *du_qp, *q1_qu, *dq1_qu, *q1_qp, *dq1_qp, *u_qf, *dq1_qf;
 };
 
+// fast diagonalisation (kernels_fdm.hip): per direction the generalised eigenvectors S (n x n row-major, columns M-orthonormal), S^T, eigenvalues
+struct FdmDir { int n = 0; DevBuf<double> S, St, lam; };
+struct FdmScalar { int dim = 0; FdmDir dir[3]; bool built = false; };
+struct FdmScale { const double *lam[3]; int n[3]; double a, k[3]; };   // divide by a + k0 lam0[i] + k1 lam1[j] + k2 lam2[k] at grid node (i, j, k)
+
 // dependency levels of the lower / upper triangle in natural row order (rows of one level can be swept concurrently)
 struct SsorLevels { DevBuf<int32_t> fwd_rows, bwd_rows; std::vector<int64_t> fwd_off, bwd_off; bool built = false; };
 struct CsrDev {
@@ -105,6 +110,7 @@ struct poro_ctx {
   poro::DevBuf<double> dinv_u, dinv_J, dinv_M;   // reciprocals of the Jacobi diagonals
   poro::DevBuf<uint8_t> diag_u_cls; poro::DevBuf<double> diag_u_tab;   // dictionary form of diag_u (uniform boxes): class per node + table[class][dim]
   poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
+  poro::FdmScalar fdm_p; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
   int n_cus = 256; int mf_variant = 1 /* 0 element-matrix gather, 1 sum-factorised (where supported) */; int mask_anywhere = 0;
@@ -176,6 +182,9 @@ void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double
 
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);
+void gen_sym_eig(int n, const std::vector<double> &K, const std::vector<double> &M, std::vector<double> &S, std::vector<double> &lam);   // host
+void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t n_outer, const double *in, double *out, const FdmScale *scale);
+void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], const double *g, double *z, double *t1, double *t2);
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
 int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr);   // returns the workgroup count (= partial slots used)
 void kron_fix_constrained(hipStream_t s, const MfArgs &a, const double *x, double *y, double *dot_partials, int slot_base);

@@ -290,31 +290,32 @@ double dot_host(poro_ctx *c, const double *a, const double *b, int64_t n) {
   double h; PORO_HIP(hipMemcpyAsync(&h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
   return h;
 }
-// SolverCG<>::solve with PreconditionSSOR, host-driven scalars (fidelity mode: many small launches per application)
-int pcg_ssor(poro_ctx *c, CsrDev &A, const double *val, double *x, const double *b, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
-  if (c->comm.multi()) throw Error("PORO_PREC_SSOR is a single-rank fidelity mode (the sweeps are order dependent)");
-  build_ssor_levels(c, A);
-  hipStream_t s = c->stream; const int64_t n = A.n; const double om = opts->omega > 0 ? opts->omega : 1.0;
+// SolverCG<>::solve with an explicit preconditioner z = P^-1 g, host-driven scalars (one rank).  Used where an application of P^-1 is
+// many launches anyway (SSOR sweeps) or where only a handful of iterations happen (fast diagonalisation).
+int pcg_host(poro_ctx *c, int64_t n, const std::function<void(const double *, double *)> &apply, const std::function<void(const double *, double *)> &precond,
+             double *x, const double *b, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
+  if (c->comm.multi()) throw Error("this preconditioner is implemented for one rank only");
+  hipStream_t s = c->stream;
   const auto t0 = std::chrono::steady_clock::now();
   const double tol = std::max(opts->abs_tol, opts->rel_tol * std::sqrt(dot_host(c, b, b, n)));
   int64_t applies = 0; int it = 0, conv = 0;
-  la_csr_spmv(s, A, val, x, g); ++applies;
+  apply(x, g); ++applies;
   la_axpy(s, g, -1.0, b, n);                                     // g = A x - b
   double res = std::sqrt(dot_host(c, g, g, n)); const double res0 = res;
   if (res <= tol) conv = 1;
   else {
-    la_ssor_apply(s, A, val, A.ssor, om, g, h);
+    precond(g, h);
     la_fill(s, d, 0.0, n); la_axpy(s, d, -1.0, h, n);          // d = -h
     double gh = dot_host(c, g, h, n);
     while (true) {
       ++it;
-      la_csr_spmv(s, A, val, d, h); ++applies;
+      apply(d, h); ++applies;
       const double alpha = gh / dot_host(c, d, h, n);
       la_axpy(s, g, alpha, h, n); la_axpy(s, x, alpha, d, n);
       res = std::sqrt(dot_host(c, g, g, n));
       if (res <= tol) { conv = 1; break; }
       if (it >= opts->max_iter) break;
-      la_ssor_apply(s, A, val, A.ssor, om, g, h);
+      precond(g, h);
       const double beta_old = gh; gh = dot_host(c, g, h, n);
       la_xpby(s, d, gh / beta_old, -1.0, h, n);                   // d = beta d - h
     }
@@ -323,6 +324,39 @@ int pcg_ssor(poro_ctx *c, CsrDev &A, const double *val, double *x, const double 
   if (info) { info->iterations = it; info->converged = conv; info->initial_residual = res0; info->final_residual = res; info->operator_applications = applies;
               info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   return conv ? 0 : 1;
+}
+int pcg_ssor(poro_ctx *c, CsrDev &A, const double *val, double *x, const double *b, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
+  if (c->comm.multi()) throw Error("PORO_PREC_SSOR is a single-rank fidelity mode (the sweeps are order dependent)");
+  build_ssor_levels(c, A);
+  const double om = opts->omega > 0 ? opts->omega : 1.0;
+  return pcg_host(c, A.n, [&](const double *v, double *y) { la_csr_spmv(c->stream, A, val, v, y); },
+                  [&](const double *gg, double *z) { la_ssor_apply(c->stream, A, val, A.ssor, om, gg, z); }, x, b, g, d, h, opts, info);
+}
+
+// ---- fast diagonalisation of the Q1 box operators (kernels_fdm.hip) -------------------------------------------------------------
+bool fdm_p_supported(poro_ctx *c) {
+  if (!c->box.enabled || c->comm.multi()) return false;
+  for (int d = 0; d < c->dim; ++d) if (c->box.n[d] + 1 > 640) return false;   // dense n x n eigenproblem on the host
+  return true;
+}
+void build_fdm_p(poro_ctx *c) {
+  if (c->fdm_p.built) return;
+  if (!fdm_p_supported(c)) throw Error("PORO_PREC_FDM needs a uniform box (poro_desc.box.enabled) on one rank");
+  c->fdm_p.dim = c->dim;
+  for (int d = 0; d < c->dim; ++d) {
+    const int n = c->box.n[d] + 1; const double h = c->box.h[d];
+    std::vector<double> M((size_t)n * n, 0.0), K((size_t)n * n, 0.0), S, lam;   // 1D Q1 mass h/6 (1 4 1), stiffness 1/h (-1 2 -1)
+    for (int e = 0; e + 1 < n; ++e) {
+      M[(size_t)e * n + e] += h / 3; M[(size_t)(e + 1) * n + e + 1] += h / 3; M[(size_t)e * n + e + 1] += h / 6; M[(size_t)(e + 1) * n + e] += h / 6;
+      K[(size_t)e * n + e] += 1 / h; K[(size_t)(e + 1) * n + e + 1] += 1 / h; K[(size_t)e * n + e + 1] -= 1 / h; K[(size_t)(e + 1) * n + e] -= 1 / h;
+    }
+    gen_sym_eig(n, K, M, S, lam);
+    std::vector<double> St((size_t)n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) St[(size_t)j * n + i] = S[(size_t)i * n + j];
+    FdmDir &D = c->fdm_p.dir[d]; D.n = n; D.S.upload(S); D.St.upload(St); D.lam.upload(lam);
+  }
+  c->fdm_t1.alloc(c->n_p); c->fdm_t2.alloc(c->n_p);
+  c->fdm_p.built = true;
 }
 
 void setup(poro_ctx *c, const poro_desc *d) {
@@ -590,11 +624,19 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
   });
 }
 
+int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec) {
+  if (!c) return 0;
+  if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
+  if (prec == PORO_PREC_SSOR) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
+  if (prec == PORO_PREC_FDM) return which_system == 1 && fdm_p_supported(c);
+  return 0;
+}
 int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *info) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
+    if (opts->preconditioner == PORO_PREC_FDM) throw Error("PORO_PREC_FDM is implemented for the pressure / projection systems (poro_supports_preconditioner)");
     if (opts->preconditioner == PORO_PREC_SSOR) {
       if (mode != PORO_OP_CSR) throw Error("PORO_PREC_SSOR needs the assembled CSR operator");
       const int rc = pcg_ssor(c, c->Au, c->Au_val.p, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
@@ -657,6 +699,13 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); }
       exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
     };
+    if (opts->preconditioner == PORO_PREC_FDM) {
+      build_fdm_p(c);
+      const double kk[3] = {jk, jk, jk};
+      return pcg_host(c, c->n_p, [&](const double *x, double *y) { apply(x, y, nullptr); },
+                      [&](const double *g, double *z) { Timed tm(c, "precondition_p_fdm"); fdm_apply(c->stream, c->fdm_p, ja, kk, g, z, c->fdm_t1.p, c->fdm_t2.p); },
+                      vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    }
     DiagVec dv; dv.full = c->dinv_J.p;
     return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
   });
@@ -711,6 +760,13 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
       else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); }
       exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
     };
+    if (opts->preconditioner == PORO_PREC_FDM) {
+      build_fdm_p(c);
+      const double kk[3] = {0, 0, 0};
+      return pcg_host(c, c->n_p, [&](const double *x, double *y) { apply(x, y, nullptr); },
+                      [&](const double *g, double *z) { Timed tm(c, "precondition_p_fdm"); fdm_apply(c->stream, c->fdm_p, 1.0, kk, g, z, c->fdm_t1.p, c->fdm_t2.p); },
+                      vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    }
     DiagVec dv; dv.full = c->dinv_M.p;
     return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
   });

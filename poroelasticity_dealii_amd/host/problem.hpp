@@ -40,7 +40,8 @@ struct RunControls {
   double p_init = 10e6, time_step = 60; int n_steps = 1;
   double fss_tol = 1e-8, pressure_tol = 1e-8; int max_fss_iterations = 50, max_pressure_iterations = 50;
   double abs_tol_u = 1e-12, rel_tol_u = 0.0; int max_iter = 1000;   // PoroElasticDisplacementSolver.h:298-299
-  int preconditioner = PORO_PREC_JACOBI;                            // PORO_PREC_SSOR = the reference's PreconditionSSOR (CSR operator, one rank)
+  int preconditioner = PORO_PREC_JACOBI;                            // displacement solve; PORO_PREC_SSOR = the reference's PreconditionSSOR (CSR operator, one rank) for all three systems
+  int preconditioner_p = -1;                                        // pressure / projection solves; -1 = fast diagonalisation where the context supports it, else Jacobi
 };
 
 }  // namespace poro_host
@@ -178,7 +179,10 @@ template <int dim> class PoroElasticProblem {
   void initialize(const RunControls &rc) {
     displacement_solver.control.abs_tol = rc.abs_tol_u; displacement_solver.control.rel_tol = rc.rel_tol_u;
     displacement_solver.control.max_iter = pressure_solver.control.max_iter = strain_projector.control.max_iter = rc.max_iter;
-    displacement_solver.control.preconditioner = pressure_solver.control.preconditioner = strain_projector.control.preconditioner = rc.preconditioner;
+    displacement_solver.control.preconditioner = rc.preconditioner;
+    pressure_solver.control.preconditioner = strain_projector.control.preconditioner =
+        rc.preconditioner == PORO_PREC_SSOR ? PORO_PREC_SSOR : rc.preconditioner_p >= 0 ? rc.preconditioner_p
+        : poro_supports_preconditioner(context(), 1, PORO_PREC_FDM) ? PORO_PREC_FDM : PORO_PREC_JACOBI;
     setup_dofs();                                          // :308
     pressure_solver.solution = rc.p_init;                  // :311
     assemble_displacement();                               // :312

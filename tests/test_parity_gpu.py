@@ -151,6 +151,49 @@ def test_ssor_cg_follows_the_reference_iteration(pair):
         F.close()
 
 
+def test_fast_diagonalisation_preconditioner(pair):
+    """PORO_PREC_FDM: on a box the pressure Jacobian (PoroElasticPressureSolver.h:158-169) and the projection mass matrix
+    (StrainProjector.h:101-106) are Kronecker sums; the preconditioner is their exact inverse, so SolverCG stops after one or
+    two iterations on the same solution the oracle's SSOR-CG converges to."""
+    P, O, G = pair
+    assert G.supports_preconditioner(1, pk.PREC_FDM) and not G.supports_preconditioner(0, pk.PREC_FDM)
+    n = G.n_p
+    vals = {pk.VEC_P: 10e6 * (1 + 0.05 * synth(n)), pk.VEC_P_OLD: 10e6 * (1 + 0.05 * synth(n, 0.2)), pk.VEC_EPSV: -2e-6 * (1 + 0.3 * synth(n, 0.5)),
+            pk.VEC_EPSV0: -2e-6 * np.ones(n)}
+    for k, v in vals.items():
+        O.set(k, v); G.set(k, v)
+    O.pres_assemble_residual(60.0); G.pres_assemble_residual(60.0)
+    O.pres_assemble_jacobian(60.0); G.pres_assemble_jacobian(60.0)
+    rc0, _ = O.pres_solve(rel_tol=1e-13); rc, info = G.pres_solve(rel_tol=1e-8, prec=pk.PREC_FDM)
+    assert rc0 == 0 and rc == 0 and info.iterations <= 2, info.iterations
+    assert info.final_residual <= 1e-12 * info.initial_residual          # exact inverse: far below the requested 1e-8
+    assert rel2(G.get(pk.VEC_DP), O.get(pk.VEC_DP)) <= 1e-9
+    u = 1e-5 * synth(G.n_u, 0.05)
+    O.set(pk.VEC_U, u); G.set(pk.VEC_U, u)
+    comps = [a * G.dim + a for a in range(G.dim)]
+    O.proj_assemble_matrix(); G.proj_assemble_matrix()
+    O.proj_assemble_rhs(comps); G.proj_assemble_rhs(comps)
+    for e in ([0, 2] if G.dim == 2 else [0, 3, 5]):
+        rc0, _ = O.proj_solve(e, rel_tol=1e-13); rc, info = G.proj_solve(e, rel_tol=1e-8, prec=pk.PREC_FDM)
+        assert rc0 == 0 and rc == 0 and info.iterations <= 2
+        assert rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
+    with pytest.raises(RuntimeError, match="pressure / projection"):
+        G.disp_assemble_system(True); G.disp_solve(prec=pk.PREC_FDM)
+
+
+def test_fast_diagonalisation_needs_a_box():
+    P = pk.Problem.gmsh(DOMAIN_MSH, 1, host_material(), BC_2D)
+    G = pk.Context(P, 0, pk.OP_CSR)
+    try:
+        assert not G.supports_preconditioner(1, pk.PREC_FDM)
+        G.fill(pk.VEC_P, 1e7); G.copy(pk.VEC_P_OLD, pk.VEC_P)
+        G.pres_assemble_residual(60.0); G.pres_assemble_jacobian(60.0)
+        with pytest.raises(RuntimeError, match="uniform box"):
+            G.pres_solve(prec=pk.PREC_FDM)
+    finally:
+        G.close(); P.close()
+
+
 def test_pressure_residual_jacobian_solve(pair):
     P, O, G = pair
     n = G.n_p
