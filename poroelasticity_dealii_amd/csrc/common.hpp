@@ -51,6 +51,9 @@ struct FeTablesDev {   // device copies of poro_fe_tables
   const double *w_qu, *w_qp, *w_qf, *u_qu, *du_qu, *du_qp, *q1_qu, *dq1_qu, *q1_qp, *dq1_qp, *u_qf, *dq1_qf;
 };
 
+// uniform-box coupling operator (kernels_box.hip): 1D local blocks N[s][t] = int phi_s psi_t, D[s][t] = int phi_s' psi_t on the unit interval
+struct BoxCoupling { int k; int n[3]; double h[3]; double N[3][2], D[3][2]; };
+
 // fast diagonalisation (kernels_fdm.hip): per direction the generalised eigenvectors S (n x n row-major, columns M-orthonormal), S^T, eigenvalues
 struct FdmDir { int n = 0; DevBuf<double> S, St, lam; };
 struct FdmScalar { int dim = 0; FdmDir dir[3]; bool built = false; };
@@ -110,6 +113,7 @@ struct poro_ctx {
   poro::DevBuf<double> dinv_u, dinv_J, dinv_M;   // reciprocals of the Jacobi diagonals
   poro::DevBuf<uint8_t> diag_u_cls; poro::DevBuf<double> diag_u_tab;   // dictionary form of diag_u (uniform boxes): class per node + table[class][dim]
   poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
+  int box_asm = 0 /* 0 off, 1 unchecked, 2 checked against the per-cell kernels */; poro::BoxCoupling box_cpl{};
   poro::FdmScalar fdm_p; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
@@ -182,6 +186,9 @@ void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double
 
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);
+BoxCoupling box_coupling(int dim, int k_u, const BoxDev &box);
+void box_rhs_u(hipStream_t s, int dim, const BoxCoupling &B, double alpha, const double *p, const double *lift, const double *neu, const uint8_t *mask, double *rhs);
+void box_proj_rhs(hipStream_t s, int dim, const BoxCoupling &B, const double *u, int n_comp, const int32_t *tensor_components, double *const *rhs);
 void gen_sym_eig(int n, const std::vector<double> &K, const std::vector<double> &M, std::vector<double> &S, std::vector<double> &lam);   // host
 void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t n_outer, const double *in, double *out, const FdmScale *scale);
 void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], const double *g, double *z, double *t1, double *t2);

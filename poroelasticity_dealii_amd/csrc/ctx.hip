@@ -374,11 +374,12 @@ void setup(poro_ctx *c, const poro_desc *d) {
   for (int64_t i = 0; i < c->n_cells * c->dpc_u; ++i) if (d->cell_dofs_u[i] < 0 || d->cell_dofs_u[i] >= c->n_u) throw Error("cell_dofs_u out of range");
   for (int64_t i = 0; i < c->n_cells * c->dpc_p; ++i) if (d->cell_dofs_p[i] < 0 || d->cell_dofs_p[i] >= c->n_p) throw Error("cell_dofs_p out of range");
   for (int64_t i = 0; i < c->n_cells * c->nv; ++i) if (d->cell_vertices[i] < 0 || d->cell_vertices[i] >= d->n_vertices) throw Error("cell_vertices out of range");
-  if (c->operator_mode == PORO_OP_MATRIX_FREE) {
-    if (!d->box.enabled) throw Error("matrix-free operator needs a structured box mesh (poro_desc.box)");
-    // the lexicographic numbering the kernel assumes must be the caller's numbering
-    int64_t nn[3] = {1, 1, 1}; for (int k = 0; k < c->dim; ++k) nn[k] = (int64_t)c->k_u * d->box.n[k] + 1;
-    if (nn[0] * nn[1] * nn[2] * c->dim != c->n_u) throw Error("box does not match n_dofs_u");
+  if (c->operator_mode == PORO_OP_MATRIX_FREE && !d->box.enabled) throw Error("matrix-free operator needs a structured box mesh (poro_desc.box)");
+  if (d->box.enabled) {
+    // the lexicographic numbering the structured kernels assume must be the caller's numbering (spot-checked on three cells)
+    int64_t nn[3] = {1, 1, 1}, np[3] = {1, 1, 1}, ncells = 1;
+    for (int k = 0; k < c->dim; ++k) { if (d->box.n[k] < 1) throw Error("box.n must be positive"); nn[k] = (int64_t)c->k_u * d->box.n[k] + 1; np[k] = (int64_t)d->box.n[k] + 1; ncells *= d->box.n[k]; }
+    if (nn[0] * nn[1] * nn[2] * c->dim != c->n_u || np[0] * np[1] * np[2] != c->n_p || ncells != c->n_cells) throw Error("box does not match n_dofs_u / n_dofs_p / n_cells");
     const int n1 = c->k_u + 1;
     const int64_t ncx = d->box.n[0], ncy = d->box.n[1];
     for (int64_t cell : {(int64_t)0, c->n_cells / 2, c->n_cells - 1}) {
@@ -387,6 +388,10 @@ void setup(poro_ctx *c, const poro_desc *d) {
         const int a = sidx % n1, b = (sidx / n1) % n1, cc = sidx / (n1 * n1);
         const int64_t node = ((ck * c->k_u + cc) * nn[1] + (cj * c->k_u + b)) * nn[0] + (ci * c->k_u + a);
         for (int k = 0; k < c->dim; ++k) if (d->cell_dofs_u[(cell * c->ns_u + sidx) * c->dim + k] != node * c->dim + k) throw Error("cell_dofs_u is not the lexicographic box numbering");
+      }
+      for (int v = 0; v < c->nv; ++v) {
+        const int a = v & 1, b = (v >> 1) & 1, cc = v >> 2;
+        if (d->cell_dofs_p[cell * c->nv + v] != ((ck + cc) * np[1] + (cj + b)) * np[0] + (ci + a)) throw Error("cell_dofs_p is not the lexicographic box numbering");
       }
     }
   }
@@ -451,6 +456,41 @@ void setup(poro_ctx *c, const poro_desc *d) {
   for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
     asm_p_matrices(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], c->Ap.rp.p, c->Ap.col.p, c->Mp.p, c->Kp.p, c->src_local.p);
   PORO_HIP(hipStreamSynchronize(s));
+
+  // uniform box: the coupling / projection right-hand sides have a structured form (kernels_box.hip); check it once against the
+  // per-cell kernels on synthetic vectors before it replaces them
+  const char *ba = std::getenv("PORO_BOX_ASM");
+  if (c->box.enabled && !(ba && std::string(ba) == "0")) {
+    c->box_cpl = box_coupling(c->dim, c->k_u, c->box);
+    if (!std::getenv("PORO_DIAG_SKIP_SELFCHECK")) {
+      std::vector<double> hp(c->n_p), hu(c->n_u);
+      for (int64_t i = 0; i < c->n_p; ++i) hp[i] = 1e7 * (1 + 0.3 * std::sin(0.37 * (double)i));
+      for (int64_t i = 0; i < c->n_u; ++i) hu[i] = 1e-5 * std::sin(0.11 * (double)i);
+      DevBuf<double> tp, tu, zero_u, r1, r2; tp.upload(hp); tu.upload(hu); zero_u.alloc(c->n_u); zero_u.zero(s); r1.alloc(c->n_u); r2.alloc(c->n_u);
+      auto compare = [&](const char *what, double *x1, const double *x2, int64_t n) {
+        la_axpy(s, x1, -1.0, x2, n);
+        la_norm_partials(s, x1, n, c->partials.p, c->partials.p + kMaxPartials); la_norm_partials(s, x2, n, c->partials.p + 2 * kMaxPartials, c->partials.p + 3 * kMaxPartials);
+        la_reduce_finish(s, c->partials.p, 4, c->red.p, 2 | 8);
+        double h[4]; PORO_HIP(hipMemcpyAsync(h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+        if (!(h[1] <= 1e-11 * h[3])) throw Error(std::string("structured ") + what + " disagrees with the per-cell kernel: max diff " + std::to_string(h[1]) + " vs max " + std::to_string(h[3]));
+      };
+      r1.zero(s);
+      for (size_t k = 0; k + 1 < c->color_off.size(); ++k) asm_u_rhs(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], tp.p, r1.p);
+      la_rhs_u_finish(s, r1.p, zero_u.p, zero_u.p, c->dir_mask.p, c->n_u);
+      box_rhs_u(s, c->dim, c->box_cpl, c->mat.biot_alpha, tp.p, zero_u.p, zero_u.p, c->dir_mask.p, r2.p);
+      compare("coupling right-hand side", r1.p, r2.p, c->n_u);
+      const int ncomp = c->dim * c->dim; int32_t comps[9]; double *o1[9], *o2[9];
+      DevBuf<double> q1, q2; q1.alloc((size_t)ncomp * c->n_p); q2.alloc((size_t)ncomp * c->n_p); q1.zero(s);
+      for (int e = 0; e < ncomp; ++e) { comps[e] = e; o1[e] = q1.p + (size_t)e * c->n_p; o2[e] = q2.p + (size_t)e * c->n_p; }
+      for (int e0 = 0; e0 < ncomp; e0 += 6) {
+        const int ne = std::min(6, ncomp - e0);
+        for (size_t k = 0; k + 1 < c->color_off.size(); ++k) asm_proj_rhs(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], tu.p, ne, comps + e0, o1 + e0);
+        box_proj_rhs(s, c->dim, c->box_cpl, tu.p, ne, comps + e0, o2 + e0);
+      }
+      compare("projection right-hand side", q1.p, q2.p, (int64_t)ncomp * c->n_p);
+    }
+    c->box_asm = 1;
+  }
 }
 
 void sync_source_vector(poro_ctx *c) {   // PORO_VEC_SOURCE_P = the assembled (rank-summed) well integral
@@ -613,10 +653,13 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
     {
       Timed tm(c, "assemble_u_rhs");
       double *rhs = vec(c, PORO_VEC_RHS_U);
-      la_fill(s, rhs, 0.0, c->n_u);                                            // rhs_vector = 0 (:204)
-      for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
-        asm_u_rhs(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], vec(c, PORO_VEC_P), rhs);
-      la_rhs_u_finish(s, rhs, c->lift_u.p, c->neumann_u.p, c->dir_mask.p, c->n_u);
+      if (c->box_asm) box_rhs_u(s, c->dim, c->box_cpl, c->mat.biot_alpha, vec(c, PORO_VEC_P), c->lift_u.p, c->neumann_u.p, c->dir_mask.p, rhs);
+      else {
+        la_fill(s, rhs, 0.0, c->n_u);                                            // rhs_vector = 0 (:204)
+        for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
+          asm_u_rhs(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], vec(c, PORO_VEC_P), rhs);
+        la_rhs_u_finish(s, rhs, c->lift_u.p, c->neumann_u.p, c->dir_mask.p, c->n_u);
+      }
     }
     exchange_add(c, vec(c, PORO_VEC_RHS_U), c->n_u, c->comm.part.plane_u);
     PORO_HIP(hipStreamSynchronize(s));
@@ -735,13 +778,16 @@ int poro_proj_assemble_rhs(poro_ctx *c, const int32_t *tensor_components, int32_
     for (int k = 0; k < n_comp; ++k) {
       if (tensor_components[k] < 0 || tensor_components[k] >= dim * dim) throw Error("tensor component out of range");
       const int e = dim == 2 ? m2[tensor_components[k]] : m3[tensor_components[k]];
-      rhs[k] = vec(c, PORO_VEC_PROJ_RHS0 + e); la_fill(c->stream, rhs[k], 0.0, c->n_p);   // :146-147
+      rhs[k] = vec(c, PORO_VEC_PROJ_RHS0 + e); if (!c->box_asm) la_fill(c->stream, rhs[k], 0.0, c->n_p);   // :146-147
     }
     {
       Timed tm(c, "projection_rhs");
-      const AsmArgs a = asm_args(c);
-      for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
-        asm_proj_rhs(c->stream, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], vec(c, PORO_VEC_U), n_comp, tensor_components, rhs);
+      if (c->box_asm) box_proj_rhs(c->stream, c->dim, c->box_cpl, vec(c, PORO_VEC_U), n_comp, tensor_components, rhs);
+      else {
+        const AsmArgs a = asm_args(c);
+        for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
+          asm_proj_rhs(c->stream, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], vec(c, PORO_VEC_U), n_comp, tensor_components, rhs);
+      }
     }
     for (int k = 0; k < n_comp; ++k) exchange_add(c, rhs[k], c->n_p, c->comm.part.plane_p);
     return 0;
