@@ -193,8 +193,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e6 * avg_apply, "launches_timed": n_apply,
-                         "note": ("operator kernel alone (as rocprofv3 reports it); the Dirichlet rows are finished by the list kernel k_kron_fix_constrained, avg %.1f us per operator application; "
-                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells) although the structured kernels read no index arrays") % (1e6 * t_fix / max(n_fix, 1))},
+                         "note": ("operator kernel alone (as rocprofv3 reports it); inside PCG the Dirichlet dofs are inert (zero residual / direction), so no row fix-up runs "
+                                  "(k_kron_fix_constrained only serves poro_apply_operator: %d launches in the timed region); "
+                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells) although the structured kernels read no index arrays") % n_fix},
             "work_per_step": {k: work[k] / args.steps for k in work},
             "kernel_only": {"apply_u_DoF_updates_per_s": (P.desc.n_dofs_u / (avg_apply + t_fix / max(n_fix, 1))) if n_apply else 0.0,
                             "seconds_by_family": {k: v[0] for k, v in kernel_time.items()}, "launches_by_family": {k: v[1] for k, v in kernel_time.items()}},

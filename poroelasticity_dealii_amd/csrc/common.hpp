@@ -44,7 +44,8 @@ struct PcgScalars {
 
 // INVERSE Jacobi diagonal handed to the PCG kernels (they multiply): the full vector of reciprocals, or (uniform boxes) a class byte
 // per node + table[class][component] of reciprocals
-struct DiagVec { const double *full = nullptr; const uint8_t *cls = nullptr; const double *tab = nullptr; int ncomp = 1; };
+// reciprocal Jacobi diagonal; a ZERO entry marks an inert (Dirichlet) dof that PCG leaves alone; `inert` is the same set as a byte mask
+struct DiagVec { const double *full = nullptr; const uint8_t *cls = nullptr; const double *tab = nullptr; int ncomp = 1; const uint8_t *inert = nullptr; };
 
 struct FeTablesDev {   // device copies of poro_fe_tables
   int nq_u, nq_p, nq_f, ns_u, ns_p;
@@ -148,7 +149,8 @@ void la_sum_strains(hipStream_t s, double *ev, const double *const *strains, int
 void la_set_constrained(hipStream_t s, double *x, const uint8_t *mask, const double *val, int64_t n);
 void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const double *neumann, const uint8_t *mask, int64_t n);
 // PCG pieces (device-side control, see solver in ctx.hip)
-void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, int64_t n);
+void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, const uint8_t *inert /*nullable*/, int64_t n);
+void la_mask_zero(hipStream_t s, double *x, const uint8_t *mask, int64_t n);
 void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials);
 void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVec &diag, int prec, int64_t n, int64_t n_owned, double *partials /*2 sets: gg, gz*/);
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red);

@@ -204,12 +204,13 @@ bool is_u_vec(int which) { return which == PORO_VEC_U || which == PORO_VEC_RHS_U
 
 // y = A_u x (+ interface exchange).  dot_partials != null asks for the block partials of x.y; returns true when they were produced
 // by the operator kernel itself (fused), false when the caller still has to launch the dot kernel.
-bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr) {
+bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr, bool fix_rows = true) {
   bool fused = false;
   if (mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
     int slots;
     { Timed tm(c, "apply_u_matrix_free"); slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials); }
-    { Timed tm(c, "apply_u_dirichlet_rows"); kron_fix_constrained(c->stream, mf_args(c), x, y, dot_partials, slots); }
+    // inside PCG the Dirichlet rows are inert (zero residual and direction), so what the structured kernel leaves there is never read
+    if (fix_rows) { Timed tm(c, "apply_u_dirichlet_rows"); kron_fix_constrained(c->stream, mf_args(c), x, y, dot_partials, slots); }
     fused = dot_partials != nullptr;
   } else {
     Timed tm(c, mode == PORO_OP_MATRIX_FREE ? "apply_u_matrix_free" : "apply_u_csr");
@@ -235,7 +236,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   int64_t applies = 0;
   // g = A x - b ; d = -P^-1 g ; gh = g.P^-1 g
   apply(x, h, nullptr); ++applies;
-  pcg_init_residual(s, g, h, b, n);
+  pcg_init_residual(s, g, h, b, diag.inert, n);
   la_dot_partials(s, b, b, n_own, part);
   pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
   pcg_scalars_sum(s, part, 3, red);
@@ -634,16 +635,17 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
       c->diag_u_cls.release(); c->diag_u_tab.release();
       if (!c->dinv_u.p) c->dinv_u.alloc(c->n_u);
       la_reciprocal(s, c->dinv_u.p, c->diag_u.p, c->n_u);
+      la_mask_zero(s, c->dinv_u.p, c->dir_mask.p, c->n_u);                       // zero reciprocal = inert Dirichlet dof (DiagVec)
       if (c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled) {
         std::vector<double> hd(c->n_u);
-        PORO_HIP(hipMemcpyAsync(hd.data(), c->diag_u.p, c->n_u * sizeof(double), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+        PORO_HIP(hipMemcpyAsync(hd.data(), c->dinv_u.p, c->n_u * sizeof(double), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
         const int nc = c->dim; const int64_t nnode = c->n_u / nc;
         struct KeyHash { size_t operator()(const std::array<double, 3> &k) const { uint64_t h = 1469598103934665603ull; for (double v : k) { uint64_t b; std::memcpy(&b, &v, 8); h = (h ^ b) * 1099511628211ull; h ^= h >> 29; } return (size_t)h; } };
         std::unordered_map<std::array<double, 3>, int, KeyHash> dict; std::vector<uint8_t> cls(nnode); std::vector<double> tab; bool ok = true;
         for (int64_t nd = 0; nd < nnode && ok; ++nd) {
           std::array<double, 3> key{0, 0, 0}; for (int k = 0; k < nc; ++k) key[k] = hd[nd * nc + k];
           auto it = dict.find(key);
-          if (it == dict.end()) { if (dict.size() >= 255) { ok = false; break; } it = dict.emplace(key, (int)dict.size()).first; for (int k = 0; k < nc; ++k) tab.push_back(1.0 / key[k]); }
+          if (it == dict.end()) { if (dict.size() >= 255) { ok = false; break; } it = dict.emplace(key, (int)dict.size()).first; for (int k = 0; k < nc; ++k) tab.push_back(key[k]); }
           cls[nd] = (uint8_t)it->second;
         }
         if (ok) { c->diag_u_cls.upload(cls); c->diag_u_tab.upload(tab); }
@@ -687,8 +689,8 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       PORO_HIP(hipStreamSynchronize(c->stream));
       return rc;
     }
-    auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp); };
-    DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim;
+    auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp, false); };
+    DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim; dv.inert = c->dir_mask.p;
     if (c->diag_u_cls.p) { dv.cls = c->diag_u_cls.p; dv.tab = c->diag_u_tab.p; }
     const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dv, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
     la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);   // constraints.distribute (:306)

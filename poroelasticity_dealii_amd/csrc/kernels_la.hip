@@ -186,8 +186,13 @@ template <int NC> __device__ inline double diag_at(const DiagRef &D, int64_t i) 
   if constexpr (NC == 0) return D.full[i];
   else { const uint32_t node = (uint32_t)i / (uint32_t)NC; return D.tab[(uint32_t)D.cls[node] * NC + ((uint32_t)i - node * NC)]; }
 }
-__global__ void k_pcg_init_residual(double *g, const double *Ax, const double *b, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) g[i] = Ax[i] - b[i];
+// inert != null: those dofs (Dirichlet rows) are kept out of the Krylov system - their residual is zero by definition, exactly as in the
+// reference, where the constrained rows of A x = b are satisfied identically by the warm start (constraints.distribute)
+__global__ void k_pcg_init_residual(double *g, const double *Ax, const double *b, const uint8_t *inert, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) g[i] = (inert && inert[i]) ? 0.0 : Ax[i] - b[i];
+}
+__global__ void k_mask_zero(double *x, const uint8_t *mask, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) if (mask[i]) x[i] = 0.0;
 }
 template <int NC> __global__ void k_pcg_first_direction(double *d, const double *g, DiagRef D, int prec, int64_t n, int64_t n_owned, double *partials) {
   __shared__ double sh[4];
@@ -249,17 +254,22 @@ template <int NC> __global__ void k_pcg_update_g_fused(PcgScalars *sc, int parit
   const double dh = red ? red[0] : sum_partials(partials_dh, sh);
   const double alpha = sc->gh2[parity] / dh;
   double gg = 0, gz = 0;
-  auto one = [&](int64_t i, double gi) { if (i < n_owned) { const double z = prec ? gi * diag_at<NC>(D, i) : gi; gg += gi * gi; gz += gi * z; } };
+  // a zero reciprocal diagonal marks an inert (Dirichlet) dof: its residual stays exactly zero whatever the operator wrote into h there
+  auto one = [&](int64_t i, double &gi) {
+    const double Di = diag_at<NC>(D, i);
+    if (Di == 0.0) { gi = 0.0; return; }
+    if (i < n_owned) { const double z = prec ? gi * Di : gi; gg += gi * gi; gz += gi * z; }
+  };
   // 16-byte accesses (two dofs per lane and step): the arrays are hipMalloc-aligned; an odd tail element goes to one thread
   const int64_t n2 = n >> 1;
   double2 *g2 = reinterpret_cast<double2 *>(g); const double2 *h2 = reinterpret_cast<const double2 *>(h);
   for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n2; q += (int64_t)gridDim.x * kBlock) {
     double2 gv = g2[q]; const double2 hv = h2[q];
     gv.x = fma(alpha, hv.x, gv.x); gv.y = fma(alpha, hv.y, gv.y);
-    g2[q] = gv;
     one(2 * q, gv.x); one(2 * q + 1, gv.y);
+    g2[q] = gv;
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { const double gi = fma(alpha, h[n - 1], g[n - 1]); g[n - 1] = gi; one(n - 1, gi); }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { double gi = fma(alpha, h[n - 1], g[n - 1]); one(n - 1, gi); g[n - 1] = gi; }
   gg = block_sum(gg, sh); gz = block_sum(gz, sh);
   store_partial(partials_out, gg); store_partial(partials_out + kMaxPartials, gz);
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
@@ -374,9 +384,10 @@ void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const doubl
 }
 // dictionary form only for 2 / 3 components and 32-bit dof indices
 static int diag_nc(const DiagVec &dv, int64_t n) { return (dv.cls && (dv.ncomp == 2 || dv.ncomp == 3) && n < (int64_t)4000000000ll) ? dv.ncomp : 0; }
-void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, int64_t n) {
-  hipLaunchKernelGGL(k_pcg_init_residual, grid_for(n), kBlock, 0, s, g, Ax, b, n);
+void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, const uint8_t *inert, int64_t n) {
+  hipLaunchKernelGGL(k_pcg_init_residual, grid_for(n), kBlock, 0, s, g, Ax, b, inert, n);
 }
+void la_mask_zero(hipStream_t s, double *x, const uint8_t *mask, int64_t n) { if (n) hipLaunchKernelGGL(k_mask_zero, grid_for(n), kBlock, 0, s, x, mask, n); }
 void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVec &dv, int prec, int64_t n, int64_t n_owned, double *partials) {
   const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp};
   switch (diag_nc(dv, n)) {
