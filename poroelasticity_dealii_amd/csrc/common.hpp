@@ -58,7 +58,17 @@ struct BoxCoupling { int k; int n[3]; double h[3]; double N[3][2], D[3][2]; };
 // fast diagonalisation (kernels_fdm.hip): per direction the generalised eigenvectors S (n x n row-major, columns M-orthonormal), S^T, eigenvalues
 struct FdmDir { int n = 0; DevBuf<double> S, St, lam; };
 struct FdmScalar { int dim = 0; FdmDir dir[3]; bool built = false; };
-struct FdmScale { const double *lam[3]; int n[3]; double a, k[3]; };   // divide by a + k0 lam0[i] + k1 lam1[j] + k2 lam2[k] at grid node (i, j, k)
+struct FdmScale { const double *lam[3]; int n[3]; double a, k[3]; int64_t ncol, col0, col_total; };   // divide by a + k0 lam0[i] + k1 lam1[j] + k2 lam2[k] at grid node (i, j, k); ncol > 0: column-distributed layout
+// partitioned (slab) form: the transforms of the leading directions are local, the last direction runs on columns gathered by an all-to-all
+struct FdmDist {
+  bool built = false; int n_ranks = 1, rank = 0;
+  std::vector<int> layers, off;                 // cell layers and first global plane of every rank
+  int ng = 0;                                   // global node planes of the last direction
+  int64_t ncol_total = 0, C = 0;                // columns (nodes of one plane) and columns per rank
+  int max_own = 0, max_nl = 0;                  // padded plane counts of the two exchanges
+  FdmDir last;                                  // global eigenvectors of the last direction
+  DevBuf<double> sendbuf, recvbuf, tz1, tz2; std::vector<double> hsend, hrecv;
+};
 
 // dependency levels of the lower / upper triangle in natural row order (rows of one level can be swept concurrently)
 struct SsorLevels { DevBuf<int32_t> fwd_rows, bwd_rows; std::vector<int64_t> fwd_off, bwd_off; bool built = false; };
@@ -115,7 +125,7 @@ struct poro_ctx {
   poro::DevBuf<uint8_t> diag_u_cls; poro::DevBuf<double> diag_u_tab;   // dictionary form of diag_u (uniform boxes): class per node + table[class][dim]
   poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
   int box_asm = 0 /* 0 off, 1 unchecked, 2 checked against the per-cell kernels */; poro::BoxCoupling box_cpl{};
-  poro::FdmScalar fdm_p; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
+  poro::FdmScalar fdm_p; poro::FdmDist fdm_dist; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
   int n_cus = 256; int mf_variant = 1 /* 0 element-matrix gather, 1 sum-factorised (where supported) */; int mask_anywhere = 0;
@@ -191,7 +201,8 @@ bool kron_supported(int dim, int k_u);
 BoxCoupling box_coupling(int dim, int k_u, const BoxDev &box);
 void box_rhs_u(hipStream_t s, int dim, const BoxCoupling &B, double alpha, const double *p, const double *lift, const double *neu, const uint8_t *mask, double *rhs);
 void box_proj_rhs(hipStream_t s, int dim, const BoxCoupling &B, const double *u, int n_comp, const int32_t *tensor_components, double *const *rhs);
-void gen_sym_eig(int n, const std::vector<double> &K, const std::vector<double> &M, std::vector<double> &S, std::vector<double> &lam);   // host
+void q1_eig(int n_cells, double h, std::vector<double> &S, std::vector<double> &lam);   // host: generalised eigenpairs of the 1D Q1 stiffness / mass matrices
+void fdm_window(hipStream_t s, double *dst, const double *src, bool to_block, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid, int64_t grid_stride, int64_t grid_col0, int64_t grid_plane0);
 void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t n_outer, const double *in, double *out, const FdmScale *scale);
 void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], const double *g, double *z, double *t1, double *t2);
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply

@@ -286,38 +286,40 @@ void build_ssor_levels(poro_ctx *c, CsrDev &A) {
   levels(true, A.ssor.fwd_rows, A.ssor.fwd_off); levels(false, A.ssor.bwd_rows, A.ssor.bwd_off);
   A.ssor.built = true;
 }
+// global dot product on the host; n = rows this rank owns (the upper shared plane belongs to the neighbour)
 double dot_host(poro_ctx *c, const double *a, const double *b, int64_t n) {
   la_dot_partials(c->stream, a, b, n, c->partials.p); la_reduce_finish(c->stream, c->partials.p, 1, c->red.p, 0);
+  allreduce_sum(c, c->red.p, 1);
   double h; PORO_HIP(hipMemcpyAsync(&h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
   return h;
 }
-// SolverCG<>::solve with an explicit preconditioner z = P^-1 g, host-driven scalars (one rank).  Used where an application of P^-1 is
-// many launches anyway (SSOR sweeps) or where only a handful of iterations happen (fast diagonalisation).
-int pcg_host(poro_ctx *c, int64_t n, const std::function<void(const double *, double *)> &apply, const std::function<void(const double *, double *)> &precond,
+// SolverCG<>::solve with an explicit preconditioner z = P^-1 g, host-driven scalars.  Used where an application of P^-1 is many
+// launches anyway (SSOR sweeps) or where only a handful of iterations happen (fast diagonalisation).  Partitioned runs: `apply` and
+// `precond` return vectors that are consistent on the shared planes; dots run over the `n_own` owned rows and are all-reduced.
+int pcg_host(poro_ctx *c, int64_t n, int64_t n_own, const std::function<void(const double *, double *)> &apply, const std::function<void(const double *, double *)> &precond,
              double *x, const double *b, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
-  if (c->comm.multi()) throw Error("this preconditioner is implemented for one rank only");
   hipStream_t s = c->stream;
   const auto t0 = std::chrono::steady_clock::now();
-  const double tol = std::max(opts->abs_tol, opts->rel_tol * std::sqrt(dot_host(c, b, b, n)));
+  const double tol = std::max(opts->abs_tol, opts->rel_tol * std::sqrt(dot_host(c, b, b, n_own)));
   int64_t applies = 0; int it = 0, conv = 0;
   apply(x, g); ++applies;
   la_axpy(s, g, -1.0, b, n);                                     // g = A x - b
-  double res = std::sqrt(dot_host(c, g, g, n)); const double res0 = res;
+  double res = std::sqrt(dot_host(c, g, g, n_own)); const double res0 = res;
   if (res <= tol) conv = 1;
   else {
     precond(g, h);
     la_fill(s, d, 0.0, n); la_axpy(s, d, -1.0, h, n);          // d = -h
-    double gh = dot_host(c, g, h, n);
+    double gh = dot_host(c, g, h, n_own);
     while (true) {
       ++it;
       apply(d, h); ++applies;
-      const double alpha = gh / dot_host(c, d, h, n);
+      const double alpha = gh / dot_host(c, d, h, n_own);
       la_axpy(s, g, alpha, h, n); la_axpy(s, x, alpha, d, n);
-      res = std::sqrt(dot_host(c, g, g, n));
+      res = std::sqrt(dot_host(c, g, g, n_own));
       if (res <= tol) { conv = 1; break; }
       if (it >= opts->max_iter) break;
       precond(g, h);
-      const double beta_old = gh; gh = dot_host(c, g, h, n);
+      const double beta_old = gh; gh = dot_host(c, g, h, n_own);
       la_xpby(s, d, gh / beta_old, -1.0, h, n);                   // d = beta d - h
     }
   }
@@ -330,34 +332,114 @@ int pcg_ssor(poro_ctx *c, CsrDev &A, const double *val, double *x, const double 
   if (c->comm.multi()) throw Error("PORO_PREC_SSOR is a single-rank fidelity mode (the sweeps are order dependent)");
   build_ssor_levels(c, A);
   const double om = opts->omega > 0 ? opts->omega : 1.0;
-  return pcg_host(c, A.n, [&](const double *v, double *y) { la_csr_spmv(c->stream, A, val, v, y); },
+  return pcg_host(c, A.n, A.n, [&](const double *v, double *y) { la_csr_spmv(c->stream, A, val, v, y); },
                   [&](const double *gg, double *z) { la_ssor_apply(c->stream, A, val, A.ssor, om, gg, z); }, x, b, g, d, h, opts, info);
 }
 
 // ---- fast diagonalisation of the Q1 box operators (kernels_fdm.hip) -------------------------------------------------------------
 bool fdm_p_supported(poro_ctx *c) {
-  if (!c->box.enabled || c->comm.multi()) return false;
-  for (int d = 0; d < c->dim; ++d) if (c->box.n[d] + 1 > 640) return false;   // dense n x n eigenproblem on the host
+  if (!c->box.enabled) return false;
+  if (c->comm.multi() && !(c->comm.nccl_comm || (c->comm.ar && c->comm.sr))) return false;
   return true;
+}
+static void upload_dir(FdmDir &D, int n_cells, double h) {
+  std::vector<double> S, lam; q1_eig(n_cells, h, S, lam);
+  const int n = n_cells + 1;
+  std::vector<double> St((size_t)n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) St[(size_t)j * n + i] = S[(size_t)i * n + j];
+  D.n = n; D.S.upload(S); D.St.upload(St); D.lam.upload(lam);
 }
 void build_fdm_p(poro_ctx *c) {
   if (c->fdm_p.built) return;
-  if (!fdm_p_supported(c)) throw Error("PORO_PREC_FDM needs a uniform box (poro_desc.box.enabled) on one rank");
+  if (!fdm_p_supported(c)) throw Error("PORO_PREC_FDM needs a uniform box (poro_desc.box.enabled) and, when partitioned, an initialised communicator");
   c->fdm_p.dim = c->dim;
-  for (int d = 0; d < c->dim; ++d) {
-    const int n = c->box.n[d] + 1; const double h = c->box.h[d];
-    std::vector<double> M((size_t)n * n, 0.0), K((size_t)n * n, 0.0), S, lam;   // 1D Q1 mass h/6 (1 4 1), stiffness 1/h (-1 2 -1)
-    for (int e = 0; e + 1 < n; ++e) {
-      M[(size_t)e * n + e] += h / 3; M[(size_t)(e + 1) * n + e + 1] += h / 3; M[(size_t)e * n + e + 1] += h / 6; M[(size_t)(e + 1) * n + e] += h / 6;
-      K[(size_t)e * n + e] += 1 / h; K[(size_t)(e + 1) * n + e + 1] += 1 / h; K[(size_t)e * n + e + 1] -= 1 / h; K[(size_t)(e + 1) * n + e] -= 1 / h;
-    }
-    gen_sym_eig(n, K, M, S, lam);
-    std::vector<double> St((size_t)n * n);
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) St[(size_t)j * n + i] = S[(size_t)i * n + j];
-    FdmDir &D = c->fdm_p.dir[d]; D.n = n; D.S.upload(S); D.St.upload(St); D.lam.upload(lam);
-  }
+  for (int d = 0; d < c->dim; ++d) upload_dir(c->fdm_p.dir[d], c->box.n[d], c->box.h[d]);   // local slab; the last direction is replaced below when partitioned
   c->fdm_t1.alloc(c->n_p); c->fdm_t2.alloc(c->n_p);
+  if (c->comm.multi()) {
+    FdmDist &F = c->fdm_dist; const int N = std::max(1, c->comm.part.n_ranks), r = c->comm.part.rank, last = c->dim - 1;
+    F.n_ranks = N; F.rank = r;
+    // every rank learns all slab thicknesses through the existing all-reduce
+    std::vector<double> lay(N, 0.0); lay[r] = c->box.n[last];
+    DevBuf<double> tmp; tmp.upload(lay);
+    for (int base = 0; base < N; base += kScalarSlots) {
+      const int m = std::min(kScalarSlots, N - base);
+      PORO_HIP(hipMemcpyAsync(c->red.p, tmp.p + base, m * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      allreduce_sum(c, c->red.p, m);
+      PORO_HIP(hipMemcpyAsync(lay.data() + base, c->red.p, m * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+    }
+    F.layers.resize(N); F.off.resize(N); int acc = 0;
+    for (int q = 0; q < N; ++q) { F.layers[q] = (int)std::lround(lay[q]); F.off[q] = acc; acc += F.layers[q]; }
+    F.ng = acc + 1;
+    F.ncol_total = 1; for (int d = 0; d < last; ++d) F.ncol_total *= c->box.n[d] + 1;
+    F.C = (F.ncol_total + N - 1) / N;
+    F.max_own = 0; F.max_nl = 0;
+    for (int q = 0; q < N; ++q) { F.max_own = std::max(F.max_own, F.layers[q] + (q == N - 1 ? 1 : 0)); F.max_nl = std::max(F.max_nl, F.layers[q] + 1); }
+    upload_dir(F.last, acc, c->box.h[last]);
+    const size_t blk = (size_t)std::max(F.max_own, F.max_nl) * F.C;
+    F.sendbuf.alloc(blk * N); F.recvbuf.alloc(blk * N); F.tz1.alloc((size_t)F.ng * F.C); F.tz2.alloc((size_t)F.ng * F.C);
+    F.built = true;
+  }
   c->fdm_p.built = true;
+}
+// every rank sends block q of `send` (blk doubles) to rank q and receives block q of `recv` from it
+void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk) {
+  Comm &cm = c->comm; const int N = cm.part.n_ranks, r = cm.part.rank;
+  Timed tm(c, "alltoall");
+  PORO_HIP(hipMemcpyAsync(recv + (size_t)r * blk, send + (size_t)r * blk, blk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (N <= 1) return;
+  if (cm.nccl_comm) {
+    ncclComm_t comm = (ncclComm_t)cm.nccl_comm;
+    PORO_NCCL(g_rccl.GroupStart());
+    for (int q = 0; q < N; ++q) if (q != r) {
+      PORO_NCCL(g_rccl.Send(send + (size_t)q * blk, blk, ncclFloat64, q, comm, c->stream));
+      PORO_NCCL(g_rccl.Recv(recv + (size_t)q * blk, blk, ncclFloat64, q, comm, c->stream));
+    }
+    PORO_NCCL(g_rccl.GroupEnd());
+  } else if (cm.sr) {
+    FdmDist &F = c->fdm_dist; F.hsend.resize(blk); F.hrecv.resize(blk);
+    for (int step = 0; step < N; ++step) {                       // pairwise schedule: at step s rank r meets (s - r) mod N, which meets r
+      const int q = ((step - r) % N + N) % N;
+      if (q == r) continue;
+      PORO_HIP(hipMemcpyAsync(F.hsend.data(), send + (size_t)q * blk, blk * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+      cm.sr(F.hsend.data(), F.hrecv.data(), blk, q, cm.user);
+      PORO_HIP(hipMemcpyAsync(recv + (size_t)q * blk, F.hrecv.data(), blk * sizeof(double), hipMemcpyHostToDevice, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+    }
+  } else throw Error("partitioned context without a communicator");
+}
+// z = (a M + sum_d k_d K_d)^-1 g for the Q1 space of the (global) box
+void fdm_precondition_p(poro_ctx *c, double a, const double k[3], const double *g, double *z) {
+  Timed tm(c, "precondition_p_fdm");
+  hipStream_t s = c->stream;
+  if (!c->comm.multi()) { fdm_apply(s, c->fdm_p, a, k, g, z, c->fdm_t1.p, c->fdm_t2.p); return; }
+  FdmDist &F = c->fdm_dist; const FdmScalar &L = c->fdm_p;
+  const int dim = c->dim, N = F.n_ranks, r = F.rank, last = dim - 1;
+  const int n0 = L.dir[0].n, nl = c->box.n[last] + 1;             // local planes incl. the shared ones
+  const int64_t SIp = F.ncol_total;
+  double *t1 = c->fdm_t1.p, *t2 = c->fdm_t2.p;
+  // leading directions: local (the shared planes are transformed by both owners)
+  const double *cur = g;
+  if (dim == 3) { fdm_transform(s, L.dir[0].St.p, n0, 1, (int64_t)L.dir[1].n * nl, g, t1, nullptr); fdm_transform(s, L.dir[1].St.p, L.dir[1].n, n0, nl, t1, t2, nullptr); cur = t2; }
+  else { fdm_transform(s, L.dir[0].St.p, n0, 1, nl, g, t1, nullptr); cur = t1; }
+  // gather whole lines of the last direction for this rank's column group
+  const int own_r = F.layers[r] + (r == N - 1 ? 1 : 0);
+  const int64_t blk1 = (int64_t)F.max_own * F.C;
+  auto ncols_of = [&](int q) { return std::max<int64_t>(0, std::min<int64_t>(F.C, F.ncol_total - (int64_t)q * F.C)); };
+  for (int q = 0; q < N; ++q) fdm_window(s, F.sendbuf.p + (size_t)q * blk1, cur, true, own_r, F.max_own, F.C, ncols_of(q), SIp, (int64_t)q * F.C, 0);
+  alltoall_blocks(c, F.sendbuf.p, F.recvbuf.p, blk1);
+  PORO_HIP(hipMemsetAsync(F.tz1.p, 0, (size_t)F.ng * F.C * sizeof(double), s));
+  for (int q = 0; q < N; ++q) fdm_window(s, F.tz1.p, F.recvbuf.p + (size_t)q * blk1, false, F.layers[q] + (q == N - 1 ? 1 : 0), F.max_own, F.C, F.C, F.C, 0, F.off[q]);
+  FdmScale sc{}; sc.a = a; sc.ncol = F.C; sc.col0 = (int64_t)r * F.C; sc.col_total = F.ncol_total;
+  for (int d = 0; d < 3; ++d) { sc.lam[d] = d < dim ? (d == last ? F.last.lam.p : L.dir[d].lam.p) : nullptr; sc.k[d] = d < dim ? k[d] : 0.0; sc.n[d] = d < dim ? (d == last ? F.ng : L.dir[d].n) : 1; }
+  fdm_transform(s, F.last.St.p, F.ng, F.C, 1, F.tz1.p, F.tz2.p, &sc);
+  fdm_transform(s, F.last.S.p, F.ng, F.C, 1, F.tz2.p, F.tz1.p, nullptr);
+  // scatter back: every rank gets all of its planes (shared ones included) of every column group
+  const int64_t blk2 = (int64_t)F.max_nl * F.C;
+  for (int q = 0; q < N; ++q) fdm_window(s, F.sendbuf.p + (size_t)q * blk2, F.tz1.p, true, F.layers[q] + 1, F.max_nl, F.C, F.C, F.C, 0, F.off[q]);
+  alltoall_blocks(c, F.sendbuf.p, F.recvbuf.p, blk2);
+  double *back = dim == 3 ? t2 : t1;
+  for (int q = 0; q < N; ++q) fdm_window(s, back, F.recvbuf.p + (size_t)q * blk2, false, nl, F.max_nl, F.C, ncols_of(q), SIp, (int64_t)q * F.C, 0);
+  if (dim == 3) { fdm_transform(s, L.dir[1].S.p, L.dir[1].n, n0, nl, t2, t1, nullptr); fdm_transform(s, L.dir[0].S.p, n0, 1, (int64_t)L.dir[1].n * nl, t1, z, nullptr); }
+  else fdm_transform(s, L.dir[0].S.p, n0, 1, nl, t1, z, nullptr);
 }
 
 void setup(poro_ctx *c, const poro_desc *d) {
@@ -747,8 +829,8 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     if (opts->preconditioner == PORO_PREC_FDM) {
       build_fdm_p(c);
       const double kk[3] = {jk, jk, jk};
-      return pcg_host(c, c->n_p, [&](const double *x, double *y) { apply(x, y, nullptr); },
-                      [&](const double *g, double *z) { Timed tm(c, "precondition_p_fdm"); fdm_apply(c->stream, c->fdm_p, ja, kk, g, z, c->fdm_t1.p, c->fdm_t2.p); },
+      return pcg_host(c, c->n_p, owned(c, c->n_p, c->comm.part.plane_p), [&](const double *x, double *y) { apply(x, y, nullptr); },
+                      [&](const double *g, double *z) { fdm_precondition_p(c, ja, kk, g, z); },
                       vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     }
     DiagVec dv; dv.full = c->dinv_J.p;
@@ -811,8 +893,8 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
     if (opts->preconditioner == PORO_PREC_FDM) {
       build_fdm_p(c);
       const double kk[3] = {0, 0, 0};
-      return pcg_host(c, c->n_p, [&](const double *x, double *y) { apply(x, y, nullptr); },
-                      [&](const double *g, double *z) { Timed tm(c, "precondition_p_fdm"); fdm_apply(c->stream, c->fdm_p, 1.0, kk, g, z, c->fdm_t1.p, c->fdm_t2.p); },
+      return pcg_host(c, c->n_p, owned(c, c->n_p, c->comm.part.plane_p), [&](const double *x, double *y) { apply(x, y, nullptr); },
+                      [&](const double *g, double *z) { fdm_precondition_p(c, 1.0, kk, g, z); },
                       vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     }
     DiagVec dv; dv.full = c->dinv_M.p;

@@ -57,11 +57,20 @@ k_fdm_dir(const double *__restrict__ T, int n_l, int64_t SI, int64_t nr, const d
       const int64_t addr = boff[c] + (int64_t)row * SI;
       double v = acc[c][q];
       if (has_scale) {
-        const int64_t n01 = (int64_t)sc.n[0] * sc.n[1];
-        const int kk = (int)(addr / n01); const int64_t rem = addr - (int64_t)kk * n01; const int jj = (int)(rem / sc.n[0]), ii = (int)(rem - (int64_t)jj * sc.n[0]);
-        double D = sc.a + sc.k[0] * sc.lam[0][ii] + sc.k[1] * sc.lam[1][jj];
-        if (sc.lam[2]) D += sc.k[2] * sc.lam[2][kk];
-        v /= D;
+        int ii, jj, kk; bool ok = true;
+        if (sc.ncol > 0) {             // column-distributed layout of the partitioned solve: [line of the last direction][ncol local columns]
+          const int line = (int)(addr / sc.ncol); const int64_t col = sc.col0 + (addr - (int64_t)line * sc.ncol);
+          ok = col < sc.col_total;     // padding columns hold zeros
+          if (sc.lam[2]) { jj = (int)(col / sc.n[0]); ii = (int)(col - (int64_t)jj * sc.n[0]); kk = line; } else { ii = (int)col; jj = line; kk = 0; }
+        } else {
+          const int64_t n01 = (int64_t)sc.n[0] * sc.n[1];
+          kk = (int)(addr / n01); const int64_t rem = addr - (int64_t)kk * n01; jj = (int)(rem / sc.n[0]); ii = (int)(rem - (int64_t)jj * sc.n[0]);
+        }
+        if (ok) {
+          double D = sc.a + sc.k[0] * sc.lam[0][ii] + sc.k[1] * sc.lam[1][jj];
+          if (sc.lam[2]) D += sc.k[2] * sc.lam[2][kk];
+          v /= D;
+        }
       }
       out[addr] = v;
     }
@@ -104,7 +113,25 @@ k_fdm_x(const double *__restrict__ T, int n_l, int64_t nr, const double *__restr
   }
 }
 
+// copy a (planes x columns) window between a strided grid and a dense, zero-padded [n_planes_pad][C] block (to_block) or back
+__global__ void k_fdm_window(double *dst, const double *src, int to_block, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid,
+                             int64_t grid_stride, int64_t grid_col0, int64_t grid_plane0) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_planes_pad * C) return;
+  const int64_t k = idx / C, cc = idx - k * C;
+  const bool valid = k < n_planes && cc < ncols_valid;
+  const int64_t g = (grid_plane0 + k) * grid_stride + grid_col0 + cc;
+  if (to_block) dst[idx] = valid ? src[g] : 0.0;
+  else if (valid) dst[g] = src[idx];
+}
+
 }  // namespace
+
+void fdm_window(hipStream_t s, double *dst, const double *src, bool to_block, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid, int64_t grid_stride,
+                int64_t grid_col0, int64_t grid_plane0) {
+  const int64_t n = (int64_t)n_planes_pad * C;
+  if (n) hipLaunchKernelGGL(k_fdm_window, (unsigned)((n + 255) / 256), 256, 0, s, dst, src, to_block ? 1 : 0, n_planes, n_planes_pad, C, ncols_valid, grid_stride, grid_col0, grid_plane0);
+}
 
 void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t n_outer, const double *in, double *out, const FdmScale *scale) {
   const int64_t nr = SI * n_outer;
@@ -120,7 +147,7 @@ void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t 
 // z = (S0 (x) S1 (x) S2) D^-1 (S0 (x) S1 (x) S2)^T g on an n0 x n1 (x n2) grid, x fastest.  t1, t2: scratch vectors of the grid size.
 void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], const double *g, double *z, double *t1, double *t2) {
   const int dim = F.dim; const int n0 = F.dir[0].n, n1 = F.dir[1].n, n2 = dim == 3 ? F.dir[2].n : 1;
-  FdmScale sc{}; sc.a = a;
+  FdmScale sc{}; sc.a = a; sc.ncol = 0;
   for (int d = 0; d < 3; ++d) { sc.lam[d] = d < dim ? F.dir[d].lam.p : nullptr; sc.k[d] = d < dim ? k[d] : 0.0; sc.n[d] = d < dim ? F.dir[d].n : 1; }
   if (dim == 2) {
     fdm_transform(s, F.dir[0].St.p, n0, 1, n1, g, t1, nullptr);
@@ -137,49 +164,27 @@ void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], c
   }
 }
 
-// ---- host side: generalised symmetric-definite eigenproblem K s = lam M s (dense, n <= ~600), cyclic Jacobi on L^-1 K L^-T ---------
-void gen_sym_eig(int n, const std::vector<double> &K, const std::vector<double> &M, std::vector<double> &S, std::vector<double> &lam) {
-  std::vector<double> L((size_t)n * n, 0.0);
-  for (int j = 0; j < n; ++j) {                                  // Cholesky M = L L^T
-    double d = M[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
-    if (!(d > 0)) throw Error("fast diagonalisation: 1D mass matrix is not positive definite");
-    L[(size_t)j * n + j] = std::sqrt(d);
-    for (int i = j + 1; i < n; ++i) {
-      double v = M[(size_t)i * n + j];
-      for (int k = 0; k < j; ++k) v -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
-      L[(size_t)i * n + j] = v / L[(size_t)j * n + j];
+// ---- host side: K1 s = lam M1 s for the 1D Q1 matrices on n cells of size h (natural boundary conditions) ---------------------------
+// M1 = h/6 tridiag(1 4 1) (corners 2), K1 = 1/h tridiag(-1 2 -1) (corners 1): the eigenvectors are the cosines s_j(i) = cos(j pi i / n),
+// lam_j = 6/h^2 (1 - cos t)/(2 + cos t), t = j pi / n (insert into an interior and a boundary row); columns scaled to s^T M1 s = 1.
+void q1_eig(int n_cells, double h, std::vector<double> &S, std::vector<double> &lam) {
+  const int n = n_cells + 1; const double pi = 3.14159265358979323846;
+  S.assign((size_t)n * n, 0.0); lam.assign(n, 0.0);
+  std::vector<double> v(n);
+  for (int j = 0; j < n; ++j) {
+    const double t = j * pi / n_cells, ct = std::cos(t);
+    lam[j] = 6.0 / (h * h) * (1.0 - ct) / (2.0 + ct);
+    for (int i = 0; i < n; ++i) v[i] = std::cos(t * i);
+    double m = 0;
+    for (int i = 0; i < n; ++i) {
+      double Mv = (i > 0 && i < n - 1 ? 4.0 : 2.0) * v[i];
+      if (i > 0) Mv += v[i - 1];
+      if (i < n - 1) Mv += v[i + 1];
+      m += v[i] * Mv * h / 6.0;
     }
+    const double sc = 1.0 / std::sqrt(m);
+    for (int i = 0; i < n; ++i) S[(size_t)i * n + j] = v[i] * sc;
   }
-  std::vector<double> C(K);                                      // C = L^-1 K L^-T: forward substitution on the columns, then on the rows
-  for (int col = 0; col < n; ++col)
-    for (int i = 0; i < n; ++i) { double v = C[(size_t)i * n + col]; for (int k = 0; k < i; ++k) v -= L[(size_t)i * n + k] * C[(size_t)k * n + col]; C[(size_t)i * n + col] = v / L[(size_t)i * n + i]; }
-  for (int row = 0; row < n; ++row)
-    for (int i = 0; i < n; ++i) { double v = C[(size_t)row * n + i]; for (int k = 0; k < i; ++k) v -= L[(size_t)i * n + k] * C[(size_t)row * n + k]; C[(size_t)row * n + i] = v / L[(size_t)i * n + i]; }
-  for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) { const double v = 0.5 * (C[(size_t)i * n + j] + C[(size_t)j * n + i]); C[(size_t)i * n + j] = C[(size_t)j * n + i] = v; }
-  std::vector<double> V((size_t)n * n, 0.0);
-  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
-  double scale = 0; for (double v : C) scale = std::max(scale, std::fabs(v));
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0;
-    for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += C[(size_t)p * n + q] * C[(size_t)p * n + q];
-    if (std::sqrt(off) <= 1e-15 * scale * n) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = C[(size_t)p * n + q];
-        if (std::fabs(apq) <= 1e-300 || std::fabs(apq) <= 1e-17 * scale) continue;
-        const double theta = (C[(size_t)q * n + q] - C[(size_t)p * n + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-        for (int k = 0; k < n; ++k) { const double ckp = C[(size_t)k * n + p], ckq = C[(size_t)k * n + q]; C[(size_t)k * n + p] = cs * ckp - sn * ckq; C[(size_t)k * n + q] = sn * ckp + cs * ckq; }
-        for (int k = 0; k < n; ++k) { const double cpk = C[(size_t)p * n + k], cqk = C[(size_t)q * n + k]; C[(size_t)p * n + k] = cs * cpk - sn * cqk; C[(size_t)q * n + k] = sn * cpk + cs * cqk; }
-        for (int k = 0; k < n; ++k) { const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q]; V[(size_t)k * n + p] = cs * vkp - sn * vkq; V[(size_t)k * n + q] = sn * vkp + cs * vkq; }
-      }
-  }
-  lam.resize(n); for (int i = 0; i < n; ++i) lam[i] = C[(size_t)i * n + i];
-  S.assign((size_t)n * n, 0.0);                                  // S = L^-T V: back substitution per column
-  for (int col = 0; col < n; ++col)
-    for (int i = n - 1; i >= 0; --i) { double v = V[(size_t)i * n + col]; for (int k = i + 1; k < n; ++k) v -= L[(size_t)k * n + i] * S[(size_t)k * n + col]; S[(size_t)i * n + col] = v / L[(size_t)i * n + i]; }
 }
 
 }  // namespace poro

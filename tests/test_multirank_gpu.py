@@ -16,9 +16,12 @@ from test_multirank_cpu import HERE, free_port, stitch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dim,n,deg,backend", [(3, (3, 3, 6), 2, "hip_mf"), (3, (4, 4, 6), 1, "hip_csr"), (2, (8, 12), 2, "hip_mf")])
-def test_two_ranks_on_one_gpu(tmp_path, dim, n, deg, backend):
-    world, port = 2, free_port()
+@pytest.mark.parametrize("world,dim,n,deg,backend", [(2, 3, (3, 3, 6), 2, "hip_mf"), (2, 3, (4, 4, 6), 1, "hip_csr"), (2, 2, (8, 12), 2, "hip_mf"),
+                                                      (3, 3, (4, 5, 7), 1, "hip_mf"), (3, 2, (9, 10), 2, "hip_mf")])
+def test_ranks_on_one_gpu(tmp_path, world, dim, n, deg, backend):
+    """2 and 3 ranks (uneven slabs, column groups that do not divide evenly): halo exchange, all-reduced dots, and the distributed
+    fast-diagonalisation solves of the pressure / projection systems (all-to-all of column groups)."""
+    port = free_port()
     outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mr_worker.py"), str(r), str(world), str(port), str(dim), ",".join(map(str, n)), str(deg), outs[r], backend])
              for r in range(world)]
@@ -31,9 +34,12 @@ def test_two_ranks_on_one_gpu(tmp_path, dim, n, deg, backend):
     nn = [deg * m + 1 for m in n]
     plane_u = dim * int(np.prod(nn[:-1])); plane_p = int(np.prod([m + 1 for m in n[:-1]]))
     off_u = [int(r["offset_u"][0]) for r in R]
-    off_p = [0, R[0]["p"].size - plane_p]
+    off_p = [0]
+    for r in R[:-1]:
+        off_p.append(off_p[-1] + r["p"].size - plane_p)
     for r in R:
         assert np.array_equal(r["trace"][1:, :3], tr[1:, :3])
+        assert np.all(r["trace"][1:, 7] <= 2 * np.maximum(r["trace"][1:, 2], 1))      # exact preconditioner: <= 2 CG iterations per pressure solve
     u = stitch([r["u"] for r in R], off_u, plane_u, P.desc.n_dofs_u)
     p = stitch([r["p"] for r in R], off_p, plane_p, P.desc.n_dofs_p)
     rhs = stitch([r["rhs_u"] for r in R], off_u, plane_u, P.desc.n_dofs_u)
@@ -63,5 +69,13 @@ def test_rccl_data_plane_single_rank(monkeypatch):
         assert O.disp_solve()[0] == 0 and G.disp_solve(max_iter=5000)[0] == 0
         assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
         assert abs(G.norm(pk.VEC_U)[0] - np.linalg.norm(O.get(pk.VEC_U))) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+        # the distributed fast-diagonalisation solve with RCCL as the communicator (1 rank: all-reduce + the self block of the all-to-all)
+        assert G.supports_preconditioner(1, pk.PREC_FDM)
+        for S in (O, G):
+            S.set(pk.VEC_P_OLD, 0.99 * p); S.fill(pk.VEC_EPSV, -2e-6); S.fill(pk.VEC_EPSV0, -2e-6)
+            S.pres_assemble_residual(60.0); S.pres_assemble_jacobian(60.0)
+        rc0, _ = O.pres_solve(rel_tol=1e-13); rc, info = G.pres_solve(prec=pk.PREC_FDM)
+        assert rc0 == 0 and rc == 0 and info.iterations <= 2
+        assert np.linalg.norm(G.get(pk.VEC_DP) - O.get(pk.VEC_DP)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_DP))
     finally:
         G.close(); O.close(); P.close()
