@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=50000)
     ap.add_argument("--cpu-n", type=int, default=9, help="cells per direction of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-out", default=None, help="write the per-step record (SURVEY 8d config 5: FSS / pressure / Krylov iteration counts, wall-clock) to this JSON file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,7 +150,9 @@ def main():
     G.timers_reset()                          # HIP events around every kernel family on the launch stream
     sync()
     t0 = time.perf_counter()
-    traces = [R.step()[0] for _ in range(args.steps)]
+    traces, step_seconds = [], []
+    for _ in range(args.steps):
+        ts = time.perf_counter(); traces.append(R.step()[0]); step_seconds.append(time.perf_counter() - ts)   # step() returns after a stream sync
     sync()
     elapsed = time.perf_counter() - t0
     after = R.work()
@@ -165,8 +168,8 @@ def main():
     alg_bytes = bytes_per_apply(dim, deg, P.desc.n_dofs_u, P.desc.n_cells, "matrix_free")
     achieved = alg_bytes / avg_apply / 1e9 if n_apply else 0.0
     t_fix, n_fix = G.timer("apply_u_dirichlet_rows")
-    kernel_time = {k: G.timer(k) for k in ("apply_u_matrix_free", "apply_u_dirichlet_rows", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr",
-                                           "halo_exchange", "allreduce")}
+    kernel_time = {k: G.timer(k) for k in ("apply_u_matrix_free", "apply_u_dirichlet_rows", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr", "apply_p_stencil",
+                                           "precondition_p_fdm", "halo_exchange", "allreduce", "alltoall")}
 
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     # tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py); null when no profile is committed
@@ -204,6 +207,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, deg, args.cpu_n, args.rel_tol)
         print(json.dumps(out), flush=True)
+        if args.trace_out:
+            # trace rows: [step, fss iteration, pressure iterations, inner pressure error, |p|_inf, error after displacement, u CG its, p CG its]
+            rec = [{"step": int(t[-1][0]), "fss_iterations": int(len(t)), "pressure_iterations": [int(r[2]) for r in t], "cg_iterations_u": [int(r[6]) for r in t],
+                    "cg_iterations_p": [int(r[7]) for r in t], "p_inf": float(t[-1][4]), "fss_error": float(t[-1][5]), "seconds": sec} for t, sec in zip(traces, step_seconds)]
+            with open(args.trace_out, "w") as f:
+                json.dump({"workload": out["config"]["workload"], "n_gpus": world, "steps": rec, "seconds_total": elapsed}, f, indent=1)
     R.close(); P.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()

@@ -38,14 +38,20 @@ k_fdm_dir(const double *__restrict__ T, int n_l, int64_t SI, int64_t nr, const d
   v4d acc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc[c] = v4d{0, 0, 0, 0};
-  for (int l0 = 0; l0 < n_l; l0 += 4) {
-    const int l = l0 + kq; const bool lv = l < n_l;
-    const double a = (aval && lv) ? Arow[l] : 0.0;
+  // 4 k-steps per trip with all 20 operand loads issued before the first MFMA: the kernel is latency-bound (operands come from L2)
+  for (int l0 = 0; l0 < n_l; l0 += 16) {
+    double a[4], b[4][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double b = (bval[c] && lv) ? in[boff[c] + (int64_t)l * SI] : 0.0;
-      acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      const int l = l0 + 4 * u + kq; const bool lv = l < n_l;
+      a[u] = (aval && lv) ? Arow[l] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[u][c] = (bval[c] && lv) ? in[boff[c] + (int64_t)l * SI] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][c], acc[c], 0, 0, 0);
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -92,14 +98,19 @@ k_fdm_x(const double *__restrict__ T, int n_l, int64_t nr, const double *__restr
   v4d acc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc[c] = v4d{0, 0, 0, 0};
-  for (int l0 = 0; l0 < n_l; l0 += 4) {
-    const int l = l0 + kq; const bool lv = l < n_l;
-    const double a = (aval && lv) ? Arow[l] : 0.0;
+  for (int l0 = 0; l0 < n_l; l0 += 16) {
+    double a[4], b[4][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double b = (bval[c] && lv) ? Brow[c][l] : 0.0;
-      acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      const int l = l0 + 4 * u + kq; const bool lv = l < n_l;
+      a[u] = (aval && lv) ? Arow[l] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[u][c] = (bval[c] && lv) ? Brow[c][l] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][c], acc[c], 0, 0, 0);
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
