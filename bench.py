@@ -69,6 +69,20 @@ def cpu_baseline(dim, degree, n, rel_tol):
                      f"(N_u={P.desc.n_dofs_u}), one time step = {dt_step:.2f} s, {w['apply_u']} A_u applications",
            "host_cpu": _cpu_name(), "host_cores_available": os.cpu_count()}
     O.close(); P.close()
+    # context figure: what the assembled-CSR data structure gives on all host cores (not the reference's serial algorithm)
+    try:
+        threads = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))   # the 1-GPU box's CPU share is 16 cores
+        n2 = 12 if dim == 3 else 192
+        P2 = pk.Problem.box(dim, [n2] * dim, [10.0] * dim, degree, material(), BC_3D[:2 * dim])
+        O2 = oracle_py.Oracle(P2, hoisted=True)
+        O2.fill(pk.VEC_P, INPUT["p_init"]); O2.disp_assemble_system(True)
+        t_spmv, t_cg = O2.bench_spmv_threads(threads, reps=20)
+        out["all_cores_csr"] = {"threads": threads, "sample": f"{dim}D Q{degree}/Q1 {n2}^{dim} cells, N_u={P2.desc.n_dofs_u}, assembled CSR A_u",
+                                "spmv_DoF_updates_per_s": P2.desc.n_dofs_u / t_spmv, "jacobi_cg_iterations_per_s": 1.0 / t_cg,
+                                "jacobi_cg_DoF_updates_per_s": P2.desc.n_dofs_u / t_cg}
+        O2.close(); P2.close()
+    except Exception as exc:                      # the headline cpu_baseline stays valid without the context figure
+        out["all_cores_csr"] = {"error": str(exc)}
     return out
 
 

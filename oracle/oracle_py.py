@@ -37,6 +37,7 @@ def load():
         L.oracle_destroy.argtypes = [C.c_void_p]
         L.oracle_destroy.restype = None
         L.oracle_set_hoisted.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_bench_spmv_threads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.oracle_set_hoisted.restype = None
         L.oracle_set_comm.argtypes = [C.c_void_p, ALLREDUCE_FN, SENDRECV_FN, C.c_void_p]
         L.oracle_set_comm.restype = None
@@ -157,6 +158,12 @@ class Oracle:
         out = (C.c_int64 * 6)()
         self.L.oracle_work_counts(self.ptr, out, int(reset))
         return dict(zip(("apply_u", "apply_p", "asm_rhs_u", "residual_p", "jacobian_p", "proj_rhs"), list(out)))
+
+    def bench_spmv_threads(self, threads, reps=20):
+        """(seconds per CSR SpMV of A_u, seconds per Jacobi-CG iteration) with the rows split over `threads` host threads"""
+        out = (C.c_double * 2)()
+        assert self.L.oracle_bench_spmv_threads(self.ptr, int(threads), int(reps), out) == 0
+        return out[0], out[1]
 
     def noconvergence_count(self):
         return self.L.oracle_noconvergence_count(self.ptr)

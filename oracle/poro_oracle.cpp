@@ -21,6 +21,7 @@
 // against the host provider's tables by the tests.
 // =====================================================================================
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -28,6 +29,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <thread>
+#include <functional>
+#include <chrono>
 #include "../include/poroel_hip.h"
 
 namespace {
@@ -617,6 +621,54 @@ int oracle_apply_operator(oracle_ctx *c, int which, const double *x, double *y) 
   Vec xv(x, x + m->n), yv(m->n); m->vmult(yv, xv);
   o->comm.exchange_add(yv, which == PORO_MAT_A_U ? o->d.part.plane_u : o->d.part.plane_p);
   std::copy(yv.begin(), yv.end(), y); return 0;
+}
+// "All host cores" context figure for the CPU baseline: CSR SpMV of the assembled A_u and Jacobi-CG iterations on it, rows split
+// over `threads` std::threads (the reference itself is serial; this is not its algorithm, only what the same data structure gives on
+// every core of the box).  out = {seconds per SpMV, seconds per CG iteration}.
+int oracle_bench_spmv_threads(oracle_ctx *c, int threads, int reps, double *out) {
+  Oracle *o = reinterpret_cast<Oracle *>(c); const Csr &A = o->A; const int64_t n = A.n;
+  if (n == 0 || threads < 1 || reps < 1) return -1;
+  Vec x(n), y(n), g(n), d(n), h(n), dinv(n);
+  for (int64_t i = 0; i < n; ++i) { x[i] = std::sin(0.37 * (double)i); dinv[i] = 1.0 / A.val[A.diag[i]]; }
+  std::vector<double> part(64 * (size_t)threads);                // one cache line per thread
+  std::atomic<int> arrived{0}; std::atomic<int> phase{0};
+  auto barrier = [&](int &local_phase) {                          // sense-reversing spin barrier; threads are spawned once
+    local_phase ^= 1;
+    if (arrived.fetch_add(1) == threads - 1) { arrived.store(0); phase.store(local_phase); }
+    else while (phase.load() != local_phase) std::this_thread::yield();
+  };
+  double t_spmv = 0, t_cg = 0; double gh_shared = 0;
+  auto worker = [&](int t) {
+    const int64_t a = n * t / threads, b = n * (t + 1) / threads; int lp = 0;
+    auto spmv = [&](const Vec &in, Vec &outv) { for (int64_t r = a; r < b; ++r) { double s = 0; for (int64_t j = A.rp[r]; j < A.rp[r + 1]; ++j) s += A.val[j] * in[A.col[j]]; outv[r] = s; } };
+    auto total = [&]() { double s = 0; for (int q = 0; q < threads; ++q) s += part[64 * (size_t)q]; return s; };
+    spmv(x, y); barrier(lp);                                      // warm-up (first touch of y by its owner)
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; ++k) { spmv(x, y); barrier(lp); }
+    if (t == 0) t_spmv = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+    // Jacobi-CG on A v = y from v = 0: same recurrences as the device kernels
+    { double s = 0; for (int64_t i = a; i < b; ++i) { g[i] = -y[i]; d[i] = dinv[i] * y[i]; x[i] = 0; s += g[i] * g[i] * dinv[i]; } part[64 * (size_t)t] = s; }
+    barrier(lp);
+    double gh = total(); barrier(lp);
+    t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; ++k) {
+      spmv(d, h);
+      { double s = 0; for (int64_t i = a; i < b; ++i) s += d[i] * h[i]; part[64 * (size_t)t] = s; }
+      barrier(lp);
+      const double alpha = gh / total(); barrier(lp);
+      { double s = 0; for (int64_t i = a; i < b; ++i) { g[i] += alpha * h[i]; x[i] += alpha * d[i]; s += g[i] * g[i] * dinv[i]; } part[64 * (size_t)t] = s; }
+      barrier(lp);
+      const double gz = total(), beta = gz / gh; gh = gz; barrier(lp);
+      for (int64_t i = a; i < b; ++i) d[i] = beta * d[i] - dinv[i] * g[i];
+      barrier(lp);
+    }
+    if (t == 0) { t_cg = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps; gh_shared = gh; }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; ++t) th.emplace_back(worker, t);
+  for (auto &q : th) q.join();
+  out[0] = t_spmv; out[1] = t_cg; (void)gh_shared;
+  return 0;
 }
 // the oracle's own FE tables, for cross-checking the host provider (same layout as poro_fe_tables)
 int oracle_fe_table(int dim, int k, int n1d_quad, int what /*0 val,1 grad,2 weights*/, double *out) {
