@@ -147,7 +147,8 @@ enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_J
 enum { PORO_VEC_U = 0, PORO_VEC_RHS_U = 1, PORO_VEC_P = 2, PORO_VEC_P_OLD = 3, PORO_VEC_DP = 4,
        PORO_VEC_RESIDUAL_P = 5, PORO_VEC_EPSV = 6, PORO_VEC_EPSV0 = 7, PORO_VEC_SOURCE_P = 8,
        PORO_VEC_STRAIN0 = 16 /* + packed symmetric entry (TensorIndexer.h:24-31) */,
-       PORO_VEC_PROJ_RHS0 = 32 /* + entry */, PORO_VEC_DIAG_U = 48 };
+       PORO_VEC_PROJ_RHS0 = 32 /* + entry */, PORO_VEC_DIAG_U = 48,
+       PORO_VEC_STRESS0 = 64 /* + packed symmetric entry: nodal effective stress (PoroelasticityFSS.h:189-224) */ };
 
 typedef struct poro_solve_info {
   int32_t iterations;
@@ -212,6 +213,9 @@ int  poro_proj_assemble_rhs(poro_ctx *ctx, const int32_t *tensor_components, int
 int  poro_proj_solve(poro_ctx *ctx, int32_t rhs_entry, const poro_solver_opts *opts, poro_solve_info *info);
 /* PoroElasticProblem<dim>::get_volumetric_strain (PoroelasticityFSS.h:179-186): eps_v = sum of normal strains */
 int  poro_get_volumetric_strain(poro_ctx *ctx);
+/* PoroElasticProblem<dim>::get_effective_stresses (PoroelasticityFSS.h:189-224): sigma' = C : eps at every pressure node, C = isotropic_gassman_tensor
+ * (ConstitutiveModel.h:45-57); PORO_VEC_STRAIN0+e -> PORO_VEC_STRESS0+e */
+int  poro_get_effective_stresses(poro_ctx *ctx);
 
 /* parity / measurement hooks */
 int  poro_export_csr_size(poro_ctx *ctx, int which, int64_t *n_rows, int64_t *nnz);

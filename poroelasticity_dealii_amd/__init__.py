@@ -18,7 +18,7 @@ PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM = 0, 1, 2, 3
 OP_CSR, OP_MATRIX_FREE = 0, 1
 MAT_A_U, MAT_MASS_P, MAT_LAPLACE_P, MAT_JACOBIAN_P = 0, 1, 2, 3
 VEC_U, VEC_RHS_U, VEC_P, VEC_P_OLD, VEC_DP, VEC_RESIDUAL_P, VEC_EPSV, VEC_EPSV0, VEC_SOURCE_P = range(9)
-VEC_STRAIN0, VEC_PROJ_RHS0, VEC_DIAG_U = 16, 32, 48
+VEC_STRAIN0, VEC_PROJ_RHS0, VEC_DIAG_U, VEC_STRESS0 = 16, 32, 48, 64
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -82,7 +82,7 @@ HIP_SYMBOLS = [
     "poro_last_error", "poro_abi_version", "poro_ctx_create", "poro_ctx_destroy", "poro_comm_unique_id", "poro_ctx_comm_init_rccl",
     "poro_ctx_comm_init_callbacks", "poro_vec_set", "poro_vec_get", "poro_vec_fill", "poro_vec_copy", "poro_vec_axpy", "poro_vec_norm",
     "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_assemble_jacobian", "poro_pres_solve",
-    "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain",
+    "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain", "poro_get_effective_stresses",
     "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_bench_operator", "poro_timers_reset", "poro_timers_enable", "poro_timers_get"]
 
 _hip = None
@@ -124,6 +124,7 @@ def load_hip():
         L.poro_proj_assemble_rhs.argtypes = [C.c_void_p, _ip, C.c_int32]
         L.poro_proj_solve.argtypes = [C.c_void_p, C.c_int32, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]
         L.poro_get_volumetric_strain.argtypes = [C.c_void_p]
+        L.poro_get_effective_stresses.argtypes = [C.c_void_p]
         L.poro_export_csr_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.poro_export_csr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), _ip, _dp]
         L.poro_apply_operator.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
@@ -162,6 +163,7 @@ def load_host():
         L.poro_host_runner_step.argtypes = [C.c_void_p, _dp, C.c_int, C.POINTER(C.c_int64)]
         L.poro_host_runner_work.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.poro_host_runner_work.restype = None
+        L.poro_host_runner_postprocess.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.poro_host_runner_free.argtypes = [C.c_void_p]
         L.poro_host_runner_free.restype = None
         _host = L
@@ -323,6 +325,9 @@ class Context:
     def get_volumetric_strain(self):
         self._chk(self.L.poro_get_volumetric_strain(self.ptr))
 
+    def get_effective_stresses(self):
+        self._chk(self.L.poro_get_effective_stresses(self.ptr))
+
     def export_csr(self, which):
         n, nnz = C.c_int64(), C.c_int64()
         self._chk(self.L.poro_export_csr_size(self.ptr, which, C.byref(n), C.byref(nnz)))
@@ -416,6 +421,11 @@ class Runner:
         if rows < 0:
             raise RuntimeError(self.H.poro_host_last_error().decode())
         return trace[:rows], dict(zip(WORK_FIELDS, list(work)))
+
+    def postprocess(self, output_dir=None, corrected=False):
+        """PoroelasticityFSS.h:409-411: shear strains, effective stresses (PORO_VEC_STRESS0+e) and, with a directory, solution-NNNN.vtk"""
+        if self.H.poro_host_runner_postprocess(self.h, output_dir.encode() if output_dir else None, int(corrected)) < 0:
+            raise RuntimeError(self.H.poro_host_last_error().decode())
 
     def work(self):
         """cumulative work counters since creation"""

@@ -156,6 +156,7 @@ void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n);
 void la_xpby(hipStream_t s, double *y, double a, double b, const double *x, int64_t n);   // y = a y + b x
 void la_ssor_apply(hipStream_t s, const CsrDev &A, const double *val, const SsorLevels &lv, double omega, const double *src, double *dst);
 void la_sum_strains(hipStream_t s, double *ev, const double *const *strains, int n, int64_t len);
+void la_effective_stress(hipStream_t s, const double *const *strains, double *const *stresses, int dim, double lam, double G, int64_t len);
 void la_set_constrained(hipStream_t s, double *x, const uint8_t *mask, const double *val, int64_t n);
 void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const double *neumann, const uint8_t *mask, int64_t n);
 // PCG pieces (device-side control, see solver in ctx.hip)

@@ -528,7 +528,8 @@ void setup(poro_ctx *c, const poro_desc *d) {
   const int n_sym = dim * (dim + 1) / 2;
   for (int id : {PORO_VEC_U, PORO_VEC_RHS_U, PORO_VEC_DIAG_U}) { c->vec[id].alloc(c->n_u); c->vec[id].zero(s); }
   for (int id : {PORO_VEC_P, PORO_VEC_P_OLD, PORO_VEC_DP, PORO_VEC_RESIDUAL_P, PORO_VEC_EPSV, PORO_VEC_EPSV0, PORO_VEC_SOURCE_P}) { c->vec[id].alloc(c->n_p); c->vec[id].zero(s); }
-  for (int e = 0; e < n_sym; ++e) { c->vec[PORO_VEC_STRAIN0 + e].alloc(c->n_p); c->vec[PORO_VEC_STRAIN0 + e].zero(s); c->vec[PORO_VEC_PROJ_RHS0 + e].alloc(c->n_p); c->vec[PORO_VEC_PROJ_RHS0 + e].zero(s); }
+  for (int e = 0; e < n_sym; ++e) { c->vec[PORO_VEC_STRAIN0 + e].alloc(c->n_p); c->vec[PORO_VEC_STRAIN0 + e].zero(s); c->vec[PORO_VEC_PROJ_RHS0 + e].alloc(c->n_p); c->vec[PORO_VEC_PROJ_RHS0 + e].zero(s);
+                                     c->vec[PORO_VEC_STRESS0 + e].alloc(c->n_p); c->vec[PORO_VEC_STRESS0 + e].zero(s); }
   for (DevBuf<double> *b : {&c->lift_u, &c->neumann_u, &c->diag_u_local, &c->wg_u, &c->wd_u, &c->wh_u}) { b->alloc(c->n_u); b->zero(s); }
   for (DevBuf<double> *b : {&c->diag_J, &c->diag_M, &c->src_local, &c->wg_p, &c->wd_p, &c->wh_p, &c->tmp_p}) { b->alloc(c->n_p); b->zero(s); }
   c->partials.alloc((size_t)4 * kMaxPartials); c->partials.zero(s); c->scal.alloc(1); c->scal.zero(s); c->red.alloc(kScalarSlots); c->red.zero(s);
@@ -909,6 +910,16 @@ int poro_get_volumetric_strain(poro_ctx *c) {
     static const int m2[4] = {0, 1, 1, 2}, m3[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
     for (int a = 0; a < dim; ++a) sp[a] = vec(c, PORO_VEC_STRAIN0 + (dim == 2 ? m2[a * dim + a] : m3[a * dim + a]));
     la_sum_strains(c->stream, vec(c, PORO_VEC_EPSV), sp, dim, c->n_p); return 0;
+  });
+}
+
+int poro_get_effective_stresses(poro_ctx *c) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    const int ne = c->dim * (c->dim + 1) / 2; const double *e[6]; double *g[6];
+    for (int k = 0; k < ne; ++k) { e[k] = vec(c, PORO_VEC_STRAIN0 + k); g[k] = vec(c, PORO_VEC_STRESS0 + k); }
+    la_effective_stress(c->stream, e, g, c->dim, c->mat.lame_lambda, c->mat.shear_G, c->n_p);
+    PORO_HIP(hipStreamSynchronize(c->stream)); return 0;
   });
 }
 

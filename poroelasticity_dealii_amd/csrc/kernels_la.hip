@@ -372,6 +372,23 @@ void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n) { if (n
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag) {
   hipLaunchKernelGGL(k_csr_diag, grid_for(A.n), kBlock, 0, s, A.n, A.diag_pos.p, val, diag);
 }
+// sigma_ij = 2 G eps_ij + lambda tr(eps) delta_ij on the packed symmetric entries (2D: xx xy yy; 3D: xx xy xz yy yz zz)
+struct SymPtrs { const double *eps[6]; double *sig[6]; };
+__global__ void k_effective_stress(SymPtrs P, int dim, double lam, double G, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int ne = dim == 2 ? 3 : 6;
+    const double tr = dim == 2 ? P.eps[0][i] + P.eps[2][i] : P.eps[0][i] + P.eps[3][i] + P.eps[5][i];
+    for (int e = 0; e < ne; ++e) {
+      const bool diag = dim == 2 ? (e == 0 || e == 2) : (e == 0 || e == 3 || e == 5);
+      P.sig[e][i] = 2.0 * G * P.eps[e][i] + (diag ? lam * tr : 0.0);
+    }
+  }
+}
+void la_effective_stress(hipStream_t s, const double *const *strains, double *const *stresses, int dim, double lam, double G, int64_t len) {
+  SymPtrs P{}; const int ne = dim == 2 ? 3 : 6;
+  for (int k = 0; k < ne; ++k) { P.eps[k] = strains[k]; P.sig[k] = stresses[k]; }
+  hipLaunchKernelGGL(k_effective_stress, grid_for(len), kBlock, 0, s, P, dim, lam, G, len);
+}
 void la_sum_strains(hipStream_t s, double *ev, const double *const *strains, int n, int64_t len) {
   StrainPtrs sp{}; for (int k = 0; k < n; ++k) sp.p[k] = strains[k];
   hipLaunchKernelGGL(k_sum_strains, grid_for(len), kBlock, 0, s, ev, sp, n, len);

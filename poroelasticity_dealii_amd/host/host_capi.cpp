@@ -138,6 +138,15 @@ int poro_host_runner_step(void *r, double *trace, int max_rows, int64_t *work) {
     return rows;
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+// tail of the time loop body (PoroelasticityFSS.h:409-411): shear strains, effective stresses and, with a directory, solution-NNNN.vtk
+int poro_host_runner_postprocess(void *r, const char *output_dir, int corrected) {
+  try {
+    auto *R = static_cast<HostRunner *>(r);
+    RunControls rc = R->rc; rc.output_dir = output_dir ? output_dir : ""; rc.corrected_postprocessing = corrected != 0;
+    if (R->dim == 2) R->p2->postprocess(rc); else R->p3->postprocess(rc);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 // cumulative work counters since creation (same layout as poro_host_runner_step's `work`)
 void poro_host_runner_work(void *r, int64_t *work) {
   auto *R = static_cast<HostRunner *>(r);

@@ -8,6 +8,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <fstream>
+#include <cstdio>
 #include "../../include/poroel_hip.h"
 #include "mesh.hpp"
 
@@ -41,6 +43,8 @@ struct RunControls {
   double fss_tol = 1e-8, pressure_tol = 1e-8; int max_fss_iterations = 50, max_pressure_iterations = 50;
   double abs_tol_u = 1e-12, rel_tol_u = 0.0; int max_iter = 1000;   // PoroElasticDisplacementSolver.h:298-299
   int preconditioner = PORO_PREC_JACOBI;                            // displacement solve; PORO_PREC_SSOR = the reference's PreconditionSSOR (CSR operator, one rank) for all three systems
+  bool corrected_postprocessing = false;                            // false = the reference's output (shear RHS never assembled, 2D "sigma_yy" shows sigma_xx); true = both fixed
+  std::string output_dir;                                           // "" = no files; the reference always writes ./solution/solution-NNNN.vtk (:285-290)
   int preconditioner_p = -1;                                        // pressure / projection solves; -1 = fast diagonalisation where the context supports it, else Jacobi
 };
 
@@ -143,10 +147,11 @@ namespace poro_host {
 template <int dim> class PoroElasticProblem {
   poro_ctx *ctx;   // declared first: the solver members below are constructed from it
  public:
-  PoroElasticProblem(ProblemData &P, int device, int operator_mode) : ctx(make_ctx(P, device, operator_mode)), pressure_solver(ctx), displacement_solver(ctx) {
+  PoroElasticProblem(ProblemData &P, int device, int operator_mode) : ctx(make_ctx(P, device, operator_mode)), pressure_solver(ctx), displacement_solver(ctx), pd(&P) {
     volumetric_strain.ctx = initial_volumetric_strain.ctx = ctx;
     volumetric_strain.id = PORO_VEC_EPSV; initial_volumetric_strain.id = PORO_VEC_EPSV0;
-    if (dim == 2) strain_tensor_volumetric_components = {0, 3}; else strain_tensor_volumetric_components = {0, 4, 8};   // :104-110
+    if (dim == 2) { strain_tensor_volumetric_components = {0, 3}; strain_tensor_shear_components = {1}; }
+    else { strain_tensor_volumetric_components = {0, 4, 8}; strain_tensor_shear_components = {1, 2, 5}; }   // :104-111
   }
   ~PoroElasticProblem() { if (ctx) poro_ctx_destroy(ctx); }
   poro_ctx *context() { return ctx; }
@@ -170,6 +175,65 @@ template <int dim> class PoroElasticProblem {
     }
   }
   void get_volumetric_strain() { check(poro_get_volumetric_strain(ctx), "get_volumetric_strain"); }   // :179-186
+  // :167-176.  The reference never assembles the shear right-hand sides (assemble_projection_rhs is only called with the volumetric
+  // components, :157), so these solves see rhs = 0 and return eps_ij = 0; `corrected` assembles them first.
+  void get_shear_strain_components(bool corrected = false) {
+    if (corrected) strain_projector.assemble_projection_rhs(strain_tensor_shear_components);
+    for (const auto &comp : strain_tensor_shear_components) strain_projector.solve_projection_system(tensor_indexer.entryIndex(comp));
+  }
+  void get_effective_stresses() { check(poro_get_effective_stresses(ctx), "get_effective_stresses"); }   // :189-224
+  // :227-291: legacy-VTK file of u, p, strains and stresses, one patch per cell with its 2^dim vertices (build_patches(min degree) = 1
+  // subdivision), fields in the reference's order.  2D quirk: the reference writes stresses[0] under the name "sigma_yy" (:257-258).
+  void output_results(unsigned int step, const std::string &dir, bool corrected = false) {
+    const ProblemData &P = *pd; const int nv = 1 << dim, k = P.d.degree_u, n1 = k + 1, ns = P.d.fe.ns_u;
+    const int64_t nc = P.d.n_cells, npts = nc * nv;
+    std::vector<double> u, p; displacement_solver.solution.get(u, P.d.n_dofs_u); pressure_solver.solution.get(p, P.d.n_dofs_p);
+    const int n_sym = dim * (dim + 1) / 2;
+    std::vector<std::vector<double>> eps(n_sym), sig(n_sym);
+    for (int e = 0; e < n_sym; ++e) { eps[e].resize(P.d.n_dofs_p); sig[e].resize(P.d.n_dofs_p);
+      check(poro_vec_get(ctx, PORO_VEC_STRAIN0 + e, eps[e].data(), P.d.n_dofs_p), "vec_get"); check(poro_vec_get(ctx, PORO_VEC_STRESS0 + e, sig[e].data(), P.d.n_dofs_p), "vec_get"); }
+    char name[64]; std::snprintf(name, sizeof name, "/solution-%04u", step);
+    std::string file = dir + name + (P.part.n_ranks > 1 ? ".r" + std::to_string(P.part.rank) : std::string()) + ".vtk";
+    std::ofstream out(file);
+    if (!out) throw std::runtime_error("cannot write " + file);
+    out.precision(12);
+    out << "# vtk DataFile Version 3.0\n#This file was generated by poroelasticity_dealii_amd (layout of deal.II DataOut::write_vtk)\nASCII\nDATASET UNSTRUCTURED_GRID\n\n";
+    out << "POINTS " << npts << " double\n";
+    for (int64_t c = 0; c < nc; ++c) for (int v = 0; v < nv; ++v) {
+      const double *x = &P.mesh.vertices[(size_t)P.mesh.cells[c * nv + v] * dim];
+      out << x[0] << ' ' << x[1] << ' ' << (dim == 3 ? x[2] : 0.0) << '\n';
+    }
+    static const int vtk2[4] = {0, 1, 3, 2}, vtk3[8] = {0, 1, 3, 2, 4, 5, 7, 6};   // lexicographic -> VTK quad / hexahedron order
+    out << "\nCELLS " << nc << ' ' << nc * (nv + 1) << '\n';
+    for (int64_t c = 0; c < nc; ++c) { out << nv; for (int v = 0; v < nv; ++v) out << '\t' << c * nv + (dim == 2 ? vtk2[v] : vtk3[v]); out << '\n'; }
+    out << "\nCELL_TYPES " << nc << '\n';
+    for (int64_t c = 0; c < nc; ++c) out << (dim == 2 ? 9 : 12) << (c + 1 < nc ? ' ' : '\n');
+    out << "POINT_DATA " << npts << '\n' << "VECTORS u double\n";
+    for (int64_t c = 0; c < nc; ++c) for (int v = 0; v < nv; ++v) {
+      const int a = (v & 1) * k, b = ((v >> 1) & 1) * k, cc = (v >> 2) * k, sidx = a + n1 * (b + n1 * cc);
+      double w[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) w[d] = u[P.dofs.cell_u[((size_t)c * ns + sidx) * dim + d]];
+      out << w[0] << ' ' << w[1] << ' ' << w[2] << '\n';
+    }
+    auto scalar = [&](const char *nm, const std::vector<double> &f) {
+      out << "SCALARS " << nm << " double 1\nLOOKUP_TABLE default\n";
+      for (int64_t c = 0; c < nc; ++c) { for (int v = 0; v < nv; ++v) out << f[P.dofs.cell_p[c * nv + v]] << ' '; }
+      out << '\n';
+    };
+    scalar("p", p); scalar("eps_xx", eps[0]); scalar("sigma_xx", sig[0]);
+    if (dim == 2) {
+      scalar("eps_xy", eps[1]); scalar("eps_yy", eps[2]); scalar("sigma_xy", sig[1]); scalar("sigma_yy", corrected ? sig[2] : sig[0]);
+    } else {
+      scalar("eps_xy", eps[1]); scalar("eps_xz", eps[2]); scalar("eps_yy", eps[3]); scalar("eps_yz", eps[4]); scalar("eps_zz", eps[5]);
+      scalar("sigma_xy", sig[1]); scalar("sigma_xz", sig[2]); scalar("sigma_yy", sig[3]); scalar("sigma_yz", sig[4]); scalar("sigma_zz", sig[5]);
+    }
+  }
+  // the tail of the time loop body (:409-411)
+  void postprocess(const RunControls &rc) {
+    get_shear_strain_components(rc.corrected_postprocessing);
+    get_effective_stresses();
+    if (!rc.output_dir.empty()) output_results((unsigned)time_step_number, rc.output_dir, rc.corrected_postprocessing);
+  }
 
   // work counters of the metric "DoF-updates in assemble + SpMV" (SURVEY 8d): operator applications and assembly passes
   struct Work { int64_t apply_u = 0, apply_p = 0, asm_rhs_u = 0, asm_matrix_u = 0, residual_p = 0, jacobian_p = 0, proj_rhs = 0;
@@ -229,7 +293,7 @@ template <int dim> class PoroElasticProblem {
     int rows = 0;
     initialize(rc);
     if (rows < max_rows) { double *r = trace + 8 * rows++; for (int i = 0; i < 8; ++i) r[i] = 0; r[6] = displacement_solver.last.iterations; }
-    for (int s = 1; s <= rc.n_steps; ++s) rows += time_step(rc, trace + 8 * rows, max_rows - rows);   // :327
+    for (int s = 1; s <= rc.n_steps; ++s) { rows += time_step(rc, trace + 8 * rows, max_rows - rows); if (!rc.output_dir.empty()) postprocess(rc); }   // :327, :409-411
     return rows;
   }
 
@@ -238,7 +302,7 @@ template <int dim> class PoroElasticProblem {
   projection::StrainProjector<dim>            strain_projector;    // :79
   indexing::TensorIndexer<dim>                tensor_indexer;      // :81
   DeviceVector volumetric_strain, initial_volumetric_strain;       // :83
-  std::vector<int> strain_tensor_volumetric_components;            // :86
+  std::vector<int> strain_tensor_volumetric_components, strain_tensor_shear_components;   // :86-87
 
  private:
   void assemble_displacement() { const bool rebuild = first_assembly; displacement_solver.assemble_system(pressure_solver.solution); first_assembly = false; work.asm_rhs_u++; if (rebuild) work.asm_matrix_u++; }
@@ -250,6 +314,7 @@ template <int dim> class PoroElasticProblem {
     get_normal_strain_components(); work.proj_rhs++;
   }
   bool first_assembly = true; int time_step_number = 0;
+  const ProblemData *pd;
   static poro_ctx *make_ctx(ProblemData &P, int device, int operator_mode) {
     poro_ctx *c = nullptr;
     check(poro_ctx_create(&P.d, device, operator_mode, &c), "poro_ctx_create");

@@ -1,8 +1,8 @@
-// Driver executable: `poro_run input.data [--mesh domain.msh] [--degree 1|2] [--matrix-free] [--ssor] [--steps N]`.
+// Driver executable: `poro_run input.data [--mesh domain.msh] [--degree 1|2] [--matrix-free] [--ssor] [--steps N] [--output DIR] [--corrected-output]`.
 // Stands in for the reference's missing code/source/Runner.cpp (code/CMakeLists.txt:8): argv[1] is the
 // parameter file (parse_command_line.h:5-27); the mesh is create_mesh()'s colorized box refined
 // `Initial refinement level` times (PoroelasticityFSS.h:418-435) unless --mesh names a Gmsh file
-// (read_mesh, :438-445).  AMR and VTK output are out of scope.
+// (read_mesh, :438-445).  --output DIR writes DIR/solution-NNNN.vtk after every step like output_results (:227-291); AMR is out of scope.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -16,13 +16,15 @@ using namespace poro_host;
 
 int main(int argc, char **argv) {
   if (argc < 2) { std::cerr << "specify the file name" << std::endl; return 1; }   // parse_command_line.h:9-13
-  std::string mesh_file; int degree = 2, op = PORO_OP_CSR, steps = -1, device = 0, prec = PORO_PREC_JACOBI;
+  std::string mesh_file; int degree = 2, op = PORO_OP_CSR, steps = -1, device = 0, prec = PORO_PREC_JACOBI; std::string output_dir; bool corrected = false;
   for (int i = 2; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--mesh") && i + 1 < argc) mesh_file = argv[++i];
     else if (!std::strcmp(argv[i], "--degree") && i + 1 < argc) degree = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--steps") && i + 1 < argc) steps = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--matrix-free")) op = PORO_OP_MATRIX_FREE;
+    else if (!std::strcmp(argv[i], "--output") && i + 1 < argc) output_dir = argv[++i];
+    else if (!std::strcmp(argv[i], "--corrected-output")) corrected = true;
     else if (!std::strcmp(argv[i], "--ssor")) prec = PORO_PREC_SSOR;   // the reference's PreconditionSSOR instead of Jacobi
     else { std::cerr << "unknown option " << argv[i] << std::endl; return 1; }
   }
@@ -43,7 +45,7 @@ int main(int argc, char **argv) {
       for (int d = 0; d < data.dim; ++d) { n[d] = 1 << data.initial_refinement_level; size[d] = data.domain_size.at(d); }
       build_box_problem(P, data.dim, n, size, degree);
     }
-    RunControls rc; rc.preconditioner = prec;
+    RunControls rc; rc.preconditioner = prec; rc.output_dir = output_dir; rc.corrected_postprocessing = corrected;
     rc.p_init = data.p_init; rc.time_step = data.time_step; rc.fss_tol = data.fss_tol; rc.pressure_tol = data.pressure_tol;
     rc.max_fss_iterations = data.max_fss_iterations; rc.max_pressure_iterations = data.max_pressure_iterations;
     int n_steps = 0; for (double t = 0; t < data.t_max; t += data.time_step) ++n_steps;   // while (time < t_max) (:327)

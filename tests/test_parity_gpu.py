@@ -366,3 +366,58 @@ def test_structured_pressure_operator(dim, n):
             assert rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
     finally:
         G.close(); O.close(); P.close()
+
+
+@pytest.mark.parametrize("dim,n,deg", [(2, 6, 2), (3, 3, 2), (3, 4, 1)])
+def test_postprocessing_stresses_and_vtk(tmp_path, dim, n, deg):
+    """Tail of the time loop body (PoroelasticityFSS.h:409-411): get_shear_strain_components (:167-176), get_effective_stresses
+    (:189-224, sigma' = C:eps with the isotropic tensor of ConstitutiveModel.h:45-57) and output_results (:227-291).
+    Reference behaviour: the shear right-hand sides are never assembled, so eps_ij (i != j) stay 0, and the 2D file shows
+    sigma_xx under the name sigma_yy; `corrected` fixes both."""
+    mat = host_material()
+    P = box_problem(dim, n, deg, mat=mat)
+    R = pk.Runner(P, device=0, operator_mode=pk.OP_MATRIX_FREE, p_init=REF["p_init"], dt=REF["dt"], max_it=5000)
+    try:
+        R.initialize(); R.step()
+        G = R.ctx
+        n_sym = dim * (dim + 1) // 2
+        shear = [1] if dim == 2 else [1, 2, 4]
+        normal = [0, 2] if dim == 2 else [0, 3, 5]
+        out = tmp_path / "solution"; out.mkdir()
+        R.postprocess(str(out))
+        eps = [G.get(pk.VEC_STRAIN0 + e) for e in range(n_sym)]; sig = [G.get(pk.VEC_STRESS0 + e) for e in range(n_sym)]
+        for e in shear:
+            assert np.all(eps[e] == 0.0) and np.all(sig[e] == 0.0)            # the reference's zero right-hand side
+        tr = sum(eps[e] for e in normal)
+        lam, mu = mat.lame_lambda, mat.shear_G
+        for e in range(n_sym):
+            want = 2 * mu * eps[e] + (lam * tr if e in normal else 0.0)
+            assert np.abs(sig[e] - want).max() <= 1e-14 * max(np.abs(want).max(), 1.0)
+        # the file: one patch per cell, fields in the reference's order
+        txt = (out / "solution-0001.vtk").read_text().split("\n")
+        nv, nc = 2 ** dim, n ** dim
+        assert txt[0] == "# vtk DataFile Version 3.0" and txt[2] == "ASCII" and txt[3] == "DATASET UNSTRUCTURED_GRID"
+        assert f"POINTS {nc * nv} double" in txt and f"CELLS {nc} {nc * (nv + 1)}" in txt and f"POINT_DATA {nc * nv}" in txt
+        names = [l.split()[1] for l in txt if l.startswith("SCALARS") or l.startswith("VECTORS")]
+        want_names = ["u", "p", "eps_xx", "sigma_xx"] + (["eps_xy", "eps_yy", "sigma_xy", "sigma_yy"] if dim == 2 else
+                                                         ["eps_xy", "eps_xz", "eps_yy", "eps_yz", "eps_zz", "sigma_xy", "sigma_xz", "sigma_yy", "sigma_yz", "sigma_zz"])
+        assert names == want_names
+
+        def field(lines, nm):
+            i = next(k for k, l in enumerate(lines) if l.startswith(f"SCALARS {nm} "))
+            return np.array(lines[i + 2].split(), dtype=float)
+        cell_p = np.ctypeslib.as_array(P.desc.cell_dofs_p, shape=(nc * nv,))
+        assert np.allclose(field(txt, "p"), G.get(pk.VEC_P)[cell_p], rtol=1e-11)
+        if dim == 2:
+            assert np.allclose(field(txt, "sigma_yy"), sig[0][cell_p], rtol=1e-11)       # the label quirk (:257-258)
+        # corrected mode: shear strains from their own right-hand sides, sigma_yy is sigma_yy
+        R.postprocess(str(out), corrected=True)
+        G.proj_assemble_rhs([1]); G.proj_solve(1, rel_tol=1e-8, prec=pk.PREC_FDM)
+        eps_xy = G.get(pk.VEC_STRAIN0 + 1)
+        assert np.abs(eps_xy).max() > 0
+        txt2 = (out / "solution-0001.vtk").read_text().split("\n")
+        assert np.allclose(field(txt2, "eps_xy"), eps_xy[cell_p], rtol=1e-9, atol=1e-22)
+        if dim == 2:
+            assert np.allclose(field(txt2, "sigma_yy"), G.get(pk.VEC_STRESS0 + 2)[cell_p], rtol=1e-11)
+    finally:
+        R.close(); P.close()
