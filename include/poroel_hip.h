@@ -140,8 +140,10 @@ typedef struct poro_solver_opts {
  * reproduces the reference's Krylov iterates, at many small launches per application - a fidelity mode, not the fast path.
  * PORO_PREC_FDM = fast diagonalisation: on a uniform box (poro_desc.box.enabled, one rank) the pressure Jacobian and the projection
  * mass matrix are sums of Kronecker products of 1D matrices and are inverted exactly by 2*dim batched dense transforms (fp64 MFMA);
- * CG keeps the reference's stopping rule and needs 1-2 iterations.  poro_supports_preconditioner() tells whether a context can. */
-enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3 };
+ * CG keeps the reference's stopping rule and needs 1-2 iterations.  poro_supports_preconditioner() tells whether a context can.
+ * PORO_PREC_ILU0 = incomplete LU on the pattern of the assembled CSR matrix (factorised on the host once per matrix, level-scheduled
+ * triangular solves on the device; one rank, moderate sizes). */
+enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3, PORO_PREC_ILU0 = 4 };
 enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };
 enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_JACOBIAN_P = 3 };
 enum { PORO_VEC_U = 0, PORO_VEC_RHS_U = 1, PORO_VEC_P = 2, PORO_VEC_P_OLD = 3, PORO_VEC_DP = 4,

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 # ids of include/poroel_hip.h
-PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM = 0, 1, 2, 3
+PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM, PREC_ILU0 = 0, 1, 2, 3, 4
 OP_CSR, OP_MATRIX_FREE = 0, 1
 MAT_A_U, MAT_MASS_P, MAT_LAPLACE_P, MAT_JACOBIAN_P = 0, 1, 2, 3
 VEC_U, VEC_RHS_U, VEC_P, VEC_P_OLD, VEC_DP, VEC_RESIDUAL_P, VEC_EPSV, VEC_EPSV0, VEC_SOURCE_P = range(9)

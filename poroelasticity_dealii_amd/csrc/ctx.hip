@@ -336,6 +336,34 @@ int pcg_ssor(poro_ctx *c, CsrDev &A, const double *val, double *x, const double 
                   [&](const double *gg, double *z) { la_ssor_apply(c->stream, A, val, A.ssor, om, gg, z); }, x, b, g, d, h, opts, info);
 }
 
+// ---- ILU(0): factorisation on the host (row-wise IKJ on A's own pattern), solves on the device ------------------------------------
+void ilu0_factor(poro_ctx *c, const CsrDev &A, const double *val, DevBuf<double> &lu_dev) {
+  std::vector<int64_t> rp(A.n + 1), dpos(A.n); std::vector<int32_t> col(A.nnz); std::vector<double> lu(A.nnz);
+  PORO_HIP(hipMemcpy(rp.data(), A.rp.p, (A.n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost)); PORO_HIP(hipMemcpy(col.data(), A.col.p, A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  PORO_HIP(hipMemcpy(dpos.data(), A.diag_pos.p, A.n * sizeof(int64_t), hipMemcpyDeviceToHost)); PORO_HIP(hipMemcpy(lu.data(), val, A.nnz * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<int64_t> where(A.n, -1);                       // column -> position in the current row
+  for (int64_t i = 0; i < A.n; ++i) {
+    for (int64_t j = rp[i]; j < rp[i + 1]; ++j) where[col[j]] = j;
+    for (int64_t kk = rp[i]; kk < dpos[i]; ++kk) {
+      const int32_t k = col[kk];
+      const double lik = lu[kk] / lu[dpos[k]];
+      lu[kk] = lik;
+      for (int64_t jj = dpos[k] + 1; jj < rp[k + 1]; ++jj) { const int64_t pos = where[col[jj]]; if (pos >= 0) lu[pos] -= lik * lu[jj]; }
+    }
+    if (!(std::fabs(lu[dpos[i]]) > 0)) throw Error("ILU(0): zero pivot in row " + std::to_string(i));
+    for (int64_t j = rp[i]; j < rp[i + 1]; ++j) where[col[j]] = -1;
+  }
+  lu_dev.upload(lu);
+}
+int pcg_ilu0(poro_ctx *c, CsrDev &A, const double *val, DevBuf<double> &lu, bool &valid, double *x, const double *b, double *g, double *d, double *h,
+             const poro_solver_opts *opts, poro_solve_info *info) {
+  if (c->comm.multi()) throw Error("PORO_PREC_ILU0 is implemented for one rank (the factorisation is sequential in the row order)");
+  build_ssor_levels(c, A);
+  if (!valid) { ilu0_factor(c, A, val, lu); valid = true; }
+  return pcg_host(c, A.n, A.n, [&](const double *v, double *y) { la_csr_spmv(c->stream, A, val, v, y); },
+                  [&](const double *gg, double *z) { la_ilu_apply(c->stream, A, lu.p, A.ssor, gg, z); }, x, b, g, d, h, opts, info);
+}
+
 // ---- fast diagonalisation of the Q1 box operators (kernels_fdm.hip) -------------------------------------------------------------
 bool fdm_p_supported(poro_ctx *c) {
   if (!c->box.enabled) return false;
@@ -733,7 +761,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
         }
         if (ok) { c->diag_u_cls.upload(cls); c->diag_u_tab.upload(tab); }
       }
-      c->matrix_built = true;
+      c->matrix_built = true; c->ilu_u_valid = false;
     }
     {
       Timed tm(c, "assemble_u_rhs");
@@ -755,7 +783,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
 int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec) {
   if (!c) return 0;
   if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
-  if (prec == PORO_PREC_SSOR) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
+  if (prec == PORO_PREC_SSOR || prec == PORO_PREC_ILU0) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
   if (prec == PORO_PREC_FDM) return which_system == 1 && fdm_p_supported(c);
   return 0;
 }
@@ -765,6 +793,13 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
     if (opts->preconditioner == PORO_PREC_FDM) throw Error("PORO_PREC_FDM is implemented for the pressure / projection systems (poro_supports_preconditioner)");
+    if (opts->preconditioner == PORO_PREC_ILU0) {
+      if (mode != PORO_OP_CSR) throw Error("PORO_PREC_ILU0 needs the assembled CSR operator");
+      const int rc = pcg_ilu0(c, c->Au, c->Au_val.p, c->ilu_u, c->ilu_u_valid, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
+      la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
+      PORO_HIP(hipStreamSynchronize(c->stream));
+      return rc;
+    }
     if (opts->preconditioner == PORO_PREC_SSOR) {
       if (mode != PORO_OP_CSR) throw Error("PORO_PREC_SSOR needs the assembled CSR operator");
       const int rc = pcg_ssor(c, c->Au, c->Au_val.p, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
@@ -810,6 +845,7 @@ int poro_pres_assemble_jacobian(poro_ctx *c, double dt) {
     exchange_add(c, c->diag_J.p, c->n_p, c->comm.part.plane_p);
     if (!c->dinv_J.p) c->dinv_J.alloc(c->n_p);
     la_reciprocal(c->stream, c->dinv_J.p, c->diag_J.p, c->n_p);
+    if (c->jac_dt != dt) c->ilu_J_valid = false;   // J = M/(M_b dt) + (k/mu) K changes with dt only
     c->jac_dt = dt;
     return 0;
   });
@@ -819,6 +855,9 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (c->jac_dt < 0) throw Error("pres_solve before pres_assemble_jacobian");
+    if (opts->preconditioner == PORO_PREC_ILU0) {
+      return pcg_ilu0(c, c->Ap, c->Jp.p, c->ilu_J, c->ilu_J_valid, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    }
     if (opts->preconditioner == PORO_PREC_SSOR) return pcg_ssor(c, c->Ap, c->Jp.p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;   // uniform box: J is a constant-coefficient stencil
     const double ja = 1. / c->mat.biot_M / c->jac_dt, jk = c->mat.k_over_mu;
@@ -884,6 +923,9 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
     PORO_HIP(hipSetDevice(c->device));
     if (!c->projection_matrix_ready) throw Error("proj_solve before proj_assemble_matrix");
     if (entry < 0 || entry >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
+    if (opts->preconditioner == PORO_PREC_ILU0) {
+      return pcg_ilu0(c, c->Ap, c->Mp.p, c->ilu_M, c->ilu_M_valid, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    }
     if (opts->preconditioner == PORO_PREC_SSOR) return pcg_ssor(c, c->Ap, c->Mp.p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;
     auto apply = [&](const double *x, double *y, double *) {

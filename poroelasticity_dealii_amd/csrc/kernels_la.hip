@@ -173,6 +173,25 @@ __global__ void k_ssor_bwd(int64_t n_lvl, const int32_t *__restrict__ rows, cons
   for (int64_t j = dpos[r] + 1; j < rp[r + 1]; ++j) s += val[j] * dst[col[j]];
   dst[r] = (dst[r] - s * om) / val[dpos[r]];
 }
+// ILU(0) solves z = U^-1 L^-1 g with the factors stored on A's pattern (unit lower L below the diagonal, U on and above it)
+__global__ void k_ilu_fwd(int64_t n_lvl, const int32_t *__restrict__ rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                          const double *__restrict__ lu, const int64_t *__restrict__ dpos, const double *__restrict__ src, double *dst) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_lvl) return;
+  const int32_t r = rows[t];
+  double s = src[r];
+  for (int64_t j = rp[r]; j < dpos[r]; ++j) s -= lu[j] * dst[col[j]];
+  dst[r] = s;
+}
+__global__ void k_ilu_bwd(int64_t n_lvl, const int32_t *__restrict__ rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                          const double *__restrict__ lu, const int64_t *__restrict__ dpos, double *dst) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_lvl) return;
+  const int32_t r = rows[t];
+  double s = dst[r];
+  for (int64_t j = dpos[r] + 1; j < rp[r + 1]; ++j) s -= lu[j] * dst[col[j]];
+  dst[r] = s / lu[dpos[r]];
+}
 __global__ void k_xpby(double *y, double a, double b, const double *x, int64_t n) {   // y = a y + b x
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] = a * y[i] + b * x[i];
 }
@@ -369,6 +388,16 @@ void la_ssor_apply(hipStream_t s, const CsrDev &A, const double *val, const Ssor
   for (size_t l = 0; l + 1 < lv.bwd_off.size(); ++l) {
     const int64_t n = lv.bwd_off[l + 1] - lv.bwd_off[l];
     hipLaunchKernelGGL(k_ssor_bwd, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, s, n, lv.bwd_rows.p + lv.bwd_off[l], A.rp.p, A.col.p, val, A.diag_pos.p, omega, dst);
+  }
+}
+void la_ilu_apply(hipStream_t s, const CsrDev &A, const double *lu, const SsorLevels &lv, const double *src, double *dst) {
+  for (size_t l = 0; l + 1 < lv.fwd_off.size(); ++l) {
+    const int64_t n = lv.fwd_off[l + 1] - lv.fwd_off[l];
+    hipLaunchKernelGGL(k_ilu_fwd, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, s, n, lv.fwd_rows.p + lv.fwd_off[l], A.rp.p, A.col.p, lu, A.diag_pos.p, src, dst);
+  }
+  for (size_t l = 0; l + 1 < lv.bwd_off.size(); ++l) {
+    const int64_t n = lv.bwd_off[l + 1] - lv.bwd_off[l];
+    hipLaunchKernelGGL(k_ilu_bwd, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, s, n, lv.bwd_rows.p + lv.bwd_off[l], A.rp.p, A.col.p, lu, A.diag_pos.p, dst);
   }
 }
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_reciprocal, grid_for(n), kBlock, 0, s, y, x, n); }
