@@ -129,6 +129,7 @@ struct poro_ctx {
   poro::FdmScalar fdm_p; poro::FdmDist fdm_dist; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
+  int interleaved_u = 0;
   int n_cus = 256; int mf_variant = 1 /* 0 element-matrix gather, 1 sum-factorised (where supported) */; int mask_anywhere = 0;
   // timing
   bool timing = false; std::map<std::string, poro::Timer> timers;
@@ -182,6 +183,7 @@ struct AsmArgs {
   const int32_t *cell_dofs_u, *cell_dofs_p; const double *cell_X;
   const uint8_t *dir_mask; const double *dir_val;
   poro_material mat;
+  int interleaved_u;   // dof = node * dim + component everywhere (lets K-asm-u look CSR positions up per node pair)
 };
 void asm_u_matrix(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t n_cells, const int64_t *rp, const int32_t *col, double *val, double *lift);
 void asm_u_element_matrix(hipStream_t s, const AsmArgs &a, int32_t cell, double *Ke);

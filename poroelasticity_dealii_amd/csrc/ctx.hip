@@ -181,6 +181,7 @@ AsmArgs asm_args(poro_ctx *c) {
   AsmArgs a{};
   a.dim = c->dim; a.k_u = c->k_u; a.ns_u = c->ns_u; a.ns_p = c->ns_p; a.nv = c->nv; a.dpc_u = c->dpc_u; a.fe = c->fe;
   a.cell_dofs_u = c->cell_dofs_u.p; a.cell_dofs_p = c->cell_dofs_p.p; a.cell_X = c->cell_X.p; a.dir_mask = c->dir_mask.p; a.dir_val = c->dir_val.p; a.mat = c->mat;
+  a.interleaved_u = c->interleaved_u;
   return a;
 }
 MfArgs mf_args(poro_ctx *c) {
@@ -485,6 +486,9 @@ void setup(poro_ctx *c, const poro_desc *d) {
   for (int64_t i = 0; i < c->n_cells * c->dpc_u; ++i) if (d->cell_dofs_u[i] < 0 || d->cell_dofs_u[i] >= c->n_u) throw Error("cell_dofs_u out of range");
   for (int64_t i = 0; i < c->n_cells * c->dpc_p; ++i) if (d->cell_dofs_p[i] < 0 || d->cell_dofs_p[i] >= c->n_p) throw Error("cell_dofs_p out of range");
   for (int64_t i = 0; i < c->n_cells * c->nv; ++i) if (d->cell_vertices[i] < 0 || d->cell_vertices[i] >= d->n_vertices) throw Error("cell_vertices out of range");
+  { bool inter = true;     // node-interleaved displacement numbering?
+    for (int64_t i = 0; i < c->n_cells * c->ns_u && inter; ++i) { const int32_t b = d->cell_dofs_u[i * c->dim]; if (b % c->dim) inter = false; for (int k = 1; k < c->dim && inter; ++k) if (d->cell_dofs_u[i * c->dim + k] != b + k) inter = false; }
+    c->interleaved_u = inter ? 1 : 0; }
   if (c->operator_mode == PORO_OP_MATRIX_FREE && !d->box.enabled) throw Error("matrix-free operator needs a structured box mesh (poro_desc.box)");
   if (d->box.enabled) {
     // the lexicographic numbering the structured kernels assume must be the caller's numbering (spot-checked on three cells)

@@ -14,7 +14,8 @@
 namespace poro {
 namespace {
 
-constexpr int kMaxNq = 27, kMaxNs = 27, kMaxDpc = 81, kMaxNv = 8;
+constexpr int kMaxNq = 27, kMaxDpc = 81, kMaxNv = 8;
+
 
 // MappingQ1: J_ab = sum_v X_v[a] dN_v/dxi_b ; returns det J, writes J^-1
 template <int DIM> __device__ inline double jacobian_inverse(const double *X /*[nv][DIM]*/, const double *dN /*[nv][DIM]*/, double *Ji /*[DIM*DIM]*/) {
@@ -51,80 +52,134 @@ __device__ inline int64_t csr_find(const int32_t *col, int64_t b, int64_t e, int
 // ---- K-asm-u: cell stiffness matrix + Dirichlet elimination + CSR scatter + lifting vector -------------
 // mode 0: scatter into CSR (constraints applied) and accumulate lift_i = -sum_{j constrained} K_ij g_j
 // mode 1: dump the raw cell matrix of `single_cell` into Ke (reference element matrix of the matrix-free operator)
-template <int DIM> __global__ void __launch_bounds__(256)
+//
+// The reference evaluates (C:eps_i):eps_j for every (i, j, q) (:230-242, ConstitutiveModel.h:9-57).  With i = (s_i, c_i), j = (s_j, c_j)
+//   K_ij = lambda H^{c_i c_j}[s_i][s_j] + G H^{c_j c_i}[s_i][s_j] + delta(c_i, c_j) G sum_d H^{dd}[s_i][s_j],
+//   H^{ab}[s][t] = sum_q JxW_q d_a phi_s(x_q) d_b phi_t(x_q)          (dim^2 small dense products, K = n_q)
+// so the quadrature work is dim^2 GEMMs of n_s x n_q x n_s per cell instead of dpc^2 n_q contractions (6x fewer flops for Q2 hexes),
+// and it is GEMM-shaped: it runs on the matrix cores (v_mfma_f64_16x16x4_f64), operands from LDS.  The CSR position of an entry is
+// looked up once per scalar node pair when the numbering is node-interleaved (dof = node * dim + component: then the dim rows of a
+// node share one column pattern made of dim-wide groups), which cuts the binary searches by dim^2.
+typedef double v4d __attribute__((ext_vector_type(4)));
+struct AsmSmem {   // carve-up of the dynamic LDS block (doubles first, then 8 / 4 / 1-byte arrays)
+  double *G, *H, *Ji, *JxW, *X, *Gval; int64_t *Rp; int32_t *Dof, *Slot; uint8_t *Dir;
+  __host__ __device__ static size_t bytes(int dim, int ns, int nq, int nv) {
+    const int dpc = ns * dim;
+    return sizeof(double) * ((size_t)nq * ns * dim + (size_t)dim * dim * ns * ns + (size_t)nq * dim * dim + nq + (size_t)nv * dim + dpc) + sizeof(int64_t) * dpc +
+           sizeof(int32_t) * ((size_t)dpc + (size_t)ns * ns) + dpc + 16;
+  }
+  __device__ AsmSmem(double *base, int dim, int ns, int nq, int nv) {
+    const int dpc = ns * dim;
+    G = base; H = G + (size_t)nq * ns * dim; Ji = H + (size_t)dim * dim * ns * ns; JxW = Ji + (size_t)nq * dim * dim; X = JxW + nq; Gval = X + (size_t)nv * dim;
+    Rp = reinterpret_cast<int64_t *>(Gval + dpc); Dof = reinterpret_cast<int32_t *>(Rp + dpc); Slot = Dof + dpc; Dir = reinterpret_cast<uint8_t *>(Slot + (size_t)ns * ns);
+  }
+};
+template <int DIM, int NT> __global__ void __launch_bounds__(NT)
 k_asm_u_matrix(AsmArgs a, const int32_t *__restrict__ cells, int32_t single_cell, int mode, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
-               double *__restrict__ val, double *__restrict__ lift, double *__restrict__ Ke) {
-  __shared__ double sG[kMaxNq * kMaxNs * DIM];   // real-space gradients [q][s][d]
-  __shared__ double sJi[kMaxNq * DIM * DIM];
-  __shared__ double sJxW[kMaxNq];
-  __shared__ double sX[kMaxNv * DIM];
-  __shared__ double sGval[kMaxDpc];
-  __shared__ int32_t sDof[kMaxDpc];
-  __shared__ uint8_t sDir[kMaxDpc];
+               double *__restrict__ val, double *__restrict__ lift, double *__restrict__ Ke, int interleaved) {
+  extern __shared__ double smem_asm[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int64_t cell = mode == 1 ? single_cell : cells[blockIdx.x];
   const int nq = a.fe.nq_u, ns = a.ns_u, dpc = a.dpc_u, nv = a.nv;
-  for (int i = tid; i < nv * DIM; i += nt) sX[i] = a.cell_X[cell * nv * DIM + i];
+  AsmSmem S(smem_asm, DIM, ns, nq, nv);
+  for (int i = tid; i < nv * DIM; i += nt) S.X[i] = a.cell_X[cell * nv * DIM + i];
   for (int i = tid; i < dpc; i += nt) {
     const int32_t dof = a.cell_dofs_u[cell * dpc + i];
-    sDof[i] = dof; const uint8_t m = a.dir_mask[dof]; sDir[i] = m; sGval[i] = m ? a.dir_val[dof] : 0.0;
+    S.Dof[i] = dof; const uint8_t m = a.dir_mask[dof]; S.Dir[i] = m; S.Gval[i] = m ? a.dir_val[dof] : 0.0;
+    if (mode == 0) S.Rp[i] = rp[dof];
   }
   __syncthreads();
   for (int q = tid; q < nq; q += nt) {
-    const double det = jacobian_inverse<DIM>(sX, a.fe.dq1_qu + (size_t)q * nv * DIM, sJi + q * DIM * DIM);
-    sJxW[q] = det * a.fe.w_qu[q];
+    const double det = jacobian_inverse<DIM>(S.X, a.fe.dq1_qu + (size_t)q * nv * DIM, S.Ji + q * DIM * DIM);
+    S.JxW[q] = det * a.fe.w_qu[q];
   }
+  // CSR slots of the scalar node pairs (independent of the quadrature work; its global loads overlap with the next phases)
+  if (mode == 0 && interleaved)
+    for (int e = tid; e < ns * ns; e += nt) {
+      const int32_t r0 = S.Dof[(e / ns) * DIM];
+      S.Slot[e] = (int32_t)(csr_find(col, rp[r0], rp[r0 + 1], S.Dof[(e % ns) * DIM]) - rp[r0]);
+    }
   __syncthreads();
-  for (int idx = tid; idx < nq * ns; idx += nt) {
+  for (int idx = tid; idx < nq * ns; idx += nt) {          // real-space gradients [q][s][d]
     const int q = idx / ns;
-    const double *gr = a.fe.du_qu + (size_t)idx * DIM, *Ji = sJi + q * DIM * DIM;
+    const double *gr = a.fe.du_qu + (size_t)idx * DIM, *Ji = S.Ji + q * DIM * DIM;
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
       double g = 0;
 #pragma unroll
       for (int b = 0; b < DIM; ++b) g += Ji[b * DIM + c] * gr[b];
-      sG[idx * DIM + c] = g;
+      S.G[idx * DIM + c] = g;
+    }
+  }
+  __syncthreads();
+  // H^{ab} = (JxW G_a)^T G_b on 16 x 16 output tiles; MFMA operand layout: A[i][k], B[k][j] with i | j = lane & 15, k = lane >> 4;
+  // D register r of a lane = row (lane >> 4) + 4 r, column lane & 15
+  {
+    const int lane = tid & 63, w = tid >> 6, nw = nt >> 6, T = (ns + 15) / 16, ntile = DIM * DIM * T * T;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = w; t < ntile; t += nw) {
+      const int ab = t / (T * T), ti = (t / T) % T, tj = t % T, ca = ab / DIM, cb = ab % DIM;
+      const int si = ti * 16 + li, sj = tj * 16 + li;
+      v4d acc = {0, 0, 0, 0};
+      for (int q0 = 0; q0 < nq; q0 += 4) {
+        const int q = q0 + lk; const bool qv = q < nq;
+        const double av = (qv && si < ns) ? S.G[(q * ns + si) * DIM + ca] * S.JxW[q] : 0.0;
+        const double bv = (qv && sj < ns) ? S.G[(q * ns + sj) * DIM + cb] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + lk + 4 * r, cc = tj * 16 + li;
+        if (row < ns && cc < ns) S.H[(size_t)ab * ns * ns + row * ns + cc] = acc[r];
+      }
     }
   }
   __syncthreads();
   const double lam = a.mat.lame_lambda, G = a.mat.shear_G;
-  // (C:eps_i):eps_j = lambda gi[ci] gj[cj] + G gi[cj] gj[ci] + G delta(ci,cj) gi.gj   (ConstitutiveModel.h:9-57)
   auto entry = [&](int i, int j) {
-    const int si = i / DIM, ci = i % DIM, sj = j / DIM, cj = j % DIM;
-    double acc = 0;
-    for (int q = 0; q < nq; ++q) {
-      const double *gi = sG + (q * ns + si) * DIM, *gj = sG + (q * ns + sj) * DIM;
-      double t = lam * gi[ci] * gj[cj] + G * gi[cj] * gj[ci];
-      if (ci == cj) {
-        double dot = 0;
+    const int si = i / DIM, ci = i % DIM, sj = j / DIM, cj = j % DIM, o = si * ns + sj, nn = ns * ns;
+    double t = lam * S.H[(ci * DIM + cj) * nn + o] + G * S.H[(cj * DIM + ci) * nn + o];
+    if (ci == cj) {
+      double tr = 0;
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) dot += gi[c] * gj[c];
-        t += G * dot;
-      }
-      acc += t * sJxW[q];
+      for (int d = 0; d < DIM; ++d) tr += S.H[(d * DIM + d) * nn + o];
+      t += G * tr;
     }
-    return acc;
+    return t;
   };
   if (mode == 1) {
     for (int e = tid; e < dpc * dpc; e += nt) Ke[e] = entry(e / dpc, e % dpc);
     return;
   }
-  for (int e = tid; e < dpc * dpc; e += nt) {
-    const int i = e / dpc, j = e % dpc;
-    if (sDir[i]) {
-      if (i == j) { const int32_t r = sDof[i]; val[csr_find(col, rp[r], rp[r + 1], r)] += fabs(entry(i, i)); }
-      continue;
+  auto pos = [&](int i, int j) -> int64_t {
+    if (interleaved) return S.Rp[i] + S.Slot[(i / DIM) * ns + (j / DIM)] + (j % DIM);
+    const int32_t r = S.Dof[i]; return csr_find(col, S.Rp[i], rp[r + 1], S.Dof[j]);
+  };
+  // read-modify-write of the CSR values in batches of 8 independent entries per thread (cells of one colour share no dof and the
+  // (i, j) pairs of a cell are distinct, so the positions never collide): the loads of a batch are in flight together
+  constexpr int U = 8;
+  for (int e0 = tid; e0 < dpc * dpc; e0 += nt * U) {
+    int64_t ps[U]; double vs[U], old[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * nt; ps[u] = -1; vs[u] = 0;
+      if (e >= dpc * dpc) continue;
+      const int i = e / dpc, j = e % dpc;
+      if (S.Dir[i]) { if (i == j) { ps[u] = pos(i, i); vs[u] = fabs(entry(i, i)); } continue; }
+      if (S.Dir[j]) continue;
+      ps[u] = pos(i, j); vs[u] = entry(i, j);
     }
-    if (sDir[j]) continue;
-    const int32_t r = sDof[i];
-    val[csr_find(col, rp[r], rp[r + 1], sDof[j])] += entry(i, j);
+#pragma unroll
+    for (int u = 0; u < U; ++u) old[u] = ps[u] >= 0 ? val[ps[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (ps[u] >= 0) val[ps[u]] = old[u] + vs[u];
   }
   // lifting of the inhomogeneous Dirichlet values: rhs_i -= sum_{j constrained} K_ij g_j (distribute_local_to_global, :281-286)
   for (int i = tid; i < dpc; i += nt) {
-    if (sDir[i]) continue;
+    if (S.Dir[i]) continue;
     double s = 0; bool any = false;
-    for (int j = 0; j < dpc; ++j) if (sDir[j] && sGval[j] != 0.0) { s += entry(i, j) * sGval[j]; any = true; }
-    if (any) lift[sDof[i]] -= s;
+    for (int j = 0; j < dpc; ++j) if (S.Dir[j] && S.Gval[j] != 0.0) { s += entry(i, j) * S.Gval[j]; any = true; }
+    if (any) lift[S.Dof[i]] -= s;
   }
 }
 
@@ -296,14 +351,35 @@ k_proj_rhs(AsmArgs a, const int32_t *__restrict__ cells, const double *__restric
 
 #define PORO_DIM_DISPATCH(dim, CALL2, CALL3) do { if ((dim) == 2) { CALL2; } else { CALL3; } } while (0)
 
+// workgroup size by cell-matrix size: the phases parallelise over n_s^2 .. dpc^2 items, and LDS (73 KB for Q2 hexes) allows two
+// workgroups per CU, so big cells take 512 threads (4 waves / SIMD resident) and small ones fewer (measured, tools/asm_bench.py)
+template <int DIM, int NT> static void launch_asm_u_nt(hipStream_t s, const AsmArgs &a, unsigned grid, const int32_t *cells, int32_t cell, int mode, const int64_t *rp, const int32_t *col,
+                                                       double *val, double *lift, double *Ke, int interleaved) {
+  const size_t lds = AsmSmem::bytes(DIM, a.ns_u, a.fe.nq_u, a.nv);
+  static bool attr_set = false;   // Q2 hexes need 73 KB of LDS per workgroup: above the 64 KB default of dynamic LDS
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_asm_u_matrix<DIM, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL((k_asm_u_matrix<DIM, NT>), grid, NT, lds, s, a, cells, cell, mode, rp, col, val, lift, Ke, interleaved);
+}
+template <int DIM> static void launch_asm_u(hipStream_t s, const AsmArgs &a, unsigned grid, const int32_t *cells, int32_t cell, int mode, const int64_t *rp, const int32_t *col, double *val,
+                                            double *lift, double *Ke, int interleaved) {
+  int nt = a.dpc_u >= 64 ? 512 : a.dpc_u >= 24 ? 128 : 64;
+  if (const char *e = std::getenv("PORO_ASM_THREADS")) nt = std::atoi(e);
+  switch (nt) {
+    case 64: launch_asm_u_nt<DIM, 64>(s, a, grid, cells, cell, mode, rp, col, val, lift, Ke, interleaved); break;
+    case 128: launch_asm_u_nt<DIM, 128>(s, a, grid, cells, cell, mode, rp, col, val, lift, Ke, interleaved); break;
+    case 512: launch_asm_u_nt<DIM, 512>(s, a, grid, cells, cell, mode, rp, col, val, lift, Ke, interleaved); break;
+    case 1024: launch_asm_u_nt<DIM, 1024>(s, a, grid, cells, cell, mode, rp, col, val, lift, Ke, interleaved); break;
+    default: launch_asm_u_nt<DIM, 256>(s, a, grid, cells, cell, mode, rp, col, val, lift, Ke, interleaved);
+  }
+}
 void asm_u_matrix(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t n, const int64_t *rp, const int32_t *col, double *val, double *lift) {
   if (!n) return;
-  PORO_DIM_DISPATCH(a.dim, hipLaunchKernelGGL(k_asm_u_matrix<2>, (unsigned)n, 256, 0, s, a, cells, 0, 0, rp, col, val, lift, (double *)nullptr),
-                    hipLaunchKernelGGL(k_asm_u_matrix<3>, (unsigned)n, 256, 0, s, a, cells, 0, 0, rp, col, val, lift, (double *)nullptr));
+  if (a.dim == 2) launch_asm_u<2>(s, a, (unsigned)n, cells, 0, 0, rp, col, val, lift, nullptr, a.interleaved_u);
+  else launch_asm_u<3>(s, a, (unsigned)n, cells, 0, 0, rp, col, val, lift, nullptr, a.interleaved_u);
 }
 void asm_u_element_matrix(hipStream_t s, const AsmArgs &a, int32_t cell, double *Ke) {
-  PORO_DIM_DISPATCH(a.dim, hipLaunchKernelGGL(k_asm_u_matrix<2>, 1, 256, 0, s, a, (const int32_t *)nullptr, cell, 1, (const int64_t *)nullptr, (const int32_t *)nullptr, (double *)nullptr, (double *)nullptr, Ke),
-                    hipLaunchKernelGGL(k_asm_u_matrix<3>, 1, 256, 0, s, a, (const int32_t *)nullptr, cell, 1, (const int64_t *)nullptr, (const int32_t *)nullptr, (double *)nullptr, (double *)nullptr, Ke));
+  if (a.dim == 2) launch_asm_u<2>(s, a, 1, nullptr, cell, 1, nullptr, nullptr, nullptr, nullptr, Ke, 0);
+  else launch_asm_u<3>(s, a, 1, nullptr, cell, 1, nullptr, nullptr, nullptr, nullptr, Ke, 0);
 }
 void asm_u_rhs(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t n, const double *p, double *rhs) {
   if (!n) return;
