@@ -209,7 +209,11 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
   bool fused = false;
   if (mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
     int slots;
-    { Timed tm(c, "apply_u_matrix_free"); slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials); }
+    if (c->timing) {   // events attached to the dispatch itself: the kernel's own duration, without the gaps to its neighbours in the stream
+      Timer &t = c->timers["apply_u_matrix_free"]; hipEvent_t e0 = event_get(), e1 = event_get();
+      slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials, e0, e1);
+      t.pending.emplace_back(e0, e1); t.launches++;
+    } else slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials);
     // inside PCG the Dirichlet rows are inert (zero residual and direction), so what the structured kernel leaves there is never read
     if (fix_rows) { Timed tm(c, "apply_u_dirichlet_rows"); kron_fix_constrained(c->stream, mf_args(c), x, y, dot_partials, slots); }
     fused = dot_partials != nullptr;

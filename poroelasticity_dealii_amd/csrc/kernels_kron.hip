@@ -18,6 +18,7 @@
 // halo rows only run the z-stage).  Out-of-domain nodes are loaded as zeros, so only the centre coefficients know about
 // the domain boundary.  No atomics; results are bitwise reproducible.  Dirichlet rows / columns handled as in k_mf_apply.
 #include "common.hpp"
+#include <hip/hip_ext.h>
 
 namespace poro {
 namespace {
@@ -461,7 +462,7 @@ void check_q2_element_matrices() {
 
 bool kron_supported(int dim, int k_u) { return dim == 3 && (k_u == 1 || k_u == 2); }
 
-int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials) {
+int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1) {
   static bool checked = false;
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
@@ -499,8 +500,9 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   const int nblk = a.nblocks;
   if (dot_partials && nblk > kMaxPartials / 2) throw Error("kron_apply: too many workgroups for the fused dot product");
   a.dot_partials = dot_partials;
-  if (ku == 2) hipLaunchKernelGGL(k_kron3_q2, (unsigned)nblk, 1024, lds, s, a, x, y);
-  else hipLaunchKernelGGL(k_kron3_q1, (unsigned)nblk, 1024, lds, s, a, x, y);
+  // ev0 / ev1 (optional): timestamps at the start / end of THIS dispatch, so the measured time is the kernel's own duration
+  if (ku == 2) hipExtLaunchKernelGGL(k_kron3_q2, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
+  else hipExtLaunchKernelGGL(k_kron3_q1, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
   return nblk;
 }
 
