@@ -42,7 +42,7 @@ struct KronConsts {
   double cc_mx[4];                             // c1..c4 * sC sMx sC   (O_y / D_y of oz / wz  -> XM)
 };
 struct KronArgs {
-  int nn[3]; int n64, nty64, has32, nty32, x0_32, nzc, chunk, nA, nblocks;   // chunk = planes per z-chunk (even); nA = workgroups with 64-lane tiles
+  int nn[3]; int n64, nty64, has32, nty32, x0_32, nzc, zunit, zq, zr, nA, nblocks;   // z-chunk zc owns zq (+1 if zc < zr) units of zunit planes, the last one also the tail; nA = workgroups with 64-lane tiles
   KronConsts k;
   const uint8_t *nodemask; int constrained, mask_anywhere;
   double *dot_partials;   // optional: per-workgroup partial of x.y over the free rows (x is zero on the Dirichlet columns after masking)
@@ -79,7 +79,7 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
   const int tid = threadIdx.x;
   const int NX = a.nn[0], NY = a.nn[1], NZ = a.nn[2];
   const int Y0 = VY * tyi - 2;
-  const int k0 = zc * a.chunk, k1 = min(NZ, k0 + a.chunk);
+  const int k0 = a.zunit * (zc * a.zq + min(zc, a.zr)), k1 = zc == a.nzc - 1 ? NZ : a.zunit * ((zc + 1) * a.zq + min(zc + 1, a.zr));
 
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lx = lane % TXN;
   const int ra = RPW == 1 ? kRows64[w] : kRows32a[w], rb = RPW == 1 ? ra : kRows32b[w];
@@ -281,7 +281,7 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
   const int tid = threadIdx.x;
   const int NX = a.nn[0], NY = a.nn[1], NZ = a.nn[2];
   const int Y0 = VY * tyi - 1;
-  const int k0 = zc * a.chunk, k1 = min(NZ, k0 + a.chunk);
+  const int k0 = a.zunit * (zc * a.zq + min(zc, a.zr)), k1 = zc == a.nzc - 1 ? NZ : a.zunit * ((zc + 1) * a.zq + min(zc + 1, a.zr));
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lx = lane % TXN;
   const int r = RPW == 1 ? w : w + 16 * (lane / TXN);
   const bool halo_wave = RPW == 1 && (w == 0 || w == 15);        // (two rows per wave: halo rows share waves with valid rows)
@@ -478,9 +478,12 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   a.nty64 = (a.nn[1] + vy64 - 1) / vy64; a.nty32 = (a.nn[1] + vy32 - 1) / vy32;
   // z-chunks: as many workgroups as fit the chip in ONE round (one 1024-thread workgroup per CU), an even number of planes each
   const int cols = a.n64 * a.nty64 + a.has32 * a.nty32;
-  int nzc = n_cus / cols; if (nzc < 1) nzc = 1;
-  int chunk = (a.nn[2] + nzc - 1) / nzc; chunk += chunk & 1; if (chunk < 8) chunk = 8;
-  a.chunk = chunk; a.nzc = (a.nn[2] + chunk - 1) / chunk;
+  // (Q2 planes come in vertex / mid pairs), balanced to within one unit; chunks of fewer than 8 planes would be mostly halo
+  a.zunit = ku == 2 ? 2 : 1;
+  const int units = a.nn[2] / a.zunit;
+  const int upc = 8 / a.zunit;                                   // units in a chunk of 8 planes
+  int nzc = n_cus / cols; if (nzc > (units + upc - 1) / upc) nzc = (units + upc - 1) / upc; if (nzc < 1) nzc = 1;
+  a.nzc = nzc; a.zq = units / nzc; a.zr = units % nzc;
   a.nA = a.n64 * a.nty64 * a.nzc; a.nblocks = a.nA + a.has32 * a.nty32 * a.nzc;
   const double lam = m.lam, G = m.G, l2g = lam + 2 * G, c[4] = {-(lam + G), lam - G, G - lam, lam + G};
   const double mdiv = ku == 2 ? 30.0 : 6.0, kmul = ku == 2 ? 1.0 / 3.0 : 1.0, sC = ku == 2 ? 1.0 / 6 : 0.5;   // scales of the integer 1D matrices
