@@ -191,10 +191,10 @@ def main():
     kernel_label = ("k_kron3_q%d (matrix-free y = A_u x, sum-factorised)" % deg) if kron else ("k_mf_apply<%d,%d> (matrix-free y = A_u x, element-matrix gather)" % (dim, deg))
     traffic = None
     try:
-        if not (dim == 3 and deg == 2 and args.n == 72):
-            raise KeyError("profile is for the default workload only")
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_kron_v3.json")) as f:
-            traffic = json.load(f)["poro::k_kron3_q2"]["hbm_bytes_per_launch"]
+        # committed PMC passes of tools/bench_ops.py on the two BASELINE meshes of the structured kernels (config 4: 72^3 Q2, config 3: 99^3 Q1)
+        key = {(2, 72): "poro::k_kron3_q2", (1, 99): "poro::k_kron3_q1"}[(deg, args.n)] if dim == 3 else None
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v7.json")) as f:
+            traffic = json.load(f)[key]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
 
