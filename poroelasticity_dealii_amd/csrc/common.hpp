@@ -45,7 +45,8 @@ struct PcgScalars {
 // INVERSE Jacobi diagonal handed to the PCG kernels (they multiply): the full vector of reciprocals, or (uniform boxes) a class byte
 // per node + table[class][component] of reciprocals
 // reciprocal Jacobi diagonal; a ZERO entry marks an inert (Dirichlet) dof that PCG leaves alone; `inert` is the same set as a byte mask
-struct DiagVec { const double *full = nullptr; const uint8_t *cls = nullptr; const double *tab = nullptr; int ncomp = 1; const uint8_t *inert = nullptr; };
+struct DiagVec { const double *full = nullptr; const uint8_t *cls = nullptr; const double *tab = nullptr; int ncomp = 1; const uint8_t *inert = nullptr;
+                 const double *z = nullptr; /* explicit preconditioner: z = P^-1 g is supplied as a vector (pcg() fills it between the two update kernels) */ };
 
 struct FeTablesDev {   // device copies of poro_fe_tables
   int nq_u, nq_p, nq_f, ns_u, ns_p;
@@ -126,6 +127,7 @@ struct poro_ctx {
   poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
   int box_asm = 0 /* 0 off, 1 unchecked, 2 checked against the per-cell kernels */; poro::BoxCoupling box_cpl{};
   poro::DevBuf<double> ilu_u, ilu_J, ilu_M; bool ilu_u_valid = false, ilu_J_valid = false, ilu_M_valid = false;   // ILU(0) factors on the CSR patterns
+  poro::DevBuf<double> wz_p;   // z = P^-1 g of an explicit preconditioner (pressure-sized systems)
   poro::FdmScalar fdm_p; poro::FdmDist fdm_dist; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;

@@ -229,10 +229,15 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
 // ---- PCG with device-side control: SolverCG<>::solve restated, Jacobi instead of SSOR ---------------
 // apply(x, y, dot_partials) as apply_A_u.  The vector kernels compute alpha / beta / the stopping test in their prologues: from the
 // block partials (single rank, 3 launches per iteration incl. the operator) or from the all-reduced scalars (partitioned).
+// precond != null: explicit preconditioner z = P^-1 g (a sequence of launches on the stream, e.g. the fast diagonalisation) written into
+// diag.z between the two update kernels; the scalars stay on the device exactly as in the Jacobi case.
 int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
-        const DiagVec &diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
+        const DiagVec &diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info,
+        const std::function<void(const double *, double *)> *precond = nullptr) {
   hipStream_t s = c->stream;
   const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
+  double *zbuf = const_cast<double *>(diag.z);
+  if (precond && !zbuf) throw Error("pcg: explicit preconditioner without a z vector");
   const int64_t n_own = owned(c, n, plane);
   const bool multi = c->comm.multi();
   double *part = c->partials.p, *red = c->red.p; PcgScalars *sc = c->scal.p;
@@ -243,13 +248,14 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   apply(x, h, nullptr); ++applies;
   pcg_init_residual(s, g, h, b, diag.inert, n);
   la_dot_partials(s, b, b, n_own, part);
+  if (precond) (*precond)(g, zbuf);
   pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
   pcg_scalars_sum(s, part, 3, red);
   allreduce_sum(c, red, 3);
   pcg_scalars_start(s, sc, red, opts->abs_tol, opts->rel_tol, opts->max_iter);
   PORO_HIP(hipMemsetAsync(part_dh, 0, kMaxPartials * sizeof(double), s));
   PcgScalars hs{};
-  int batch = 4, it = 0;
+  int batch = precond ? 1 : 4, it = 0;   // an explicit preconditioner is expensive and strong: poll after every iteration at first
   while (true) {
     PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
     if (hs.done || hs.finishing) break;
@@ -261,6 +267,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
       ++applies;
       if (multi) { pcg_scalars_sum(s, part_dh, 1, red); allreduce_sum(c, red, 1); }
       pcg_update_g_fused(s, sc, (it - 1) & 1, g, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
+      if (precond) { (*precond)(g, zbuf); la_dot_partials(s, g, zbuf, n_own, part + kMaxPartials); }
       if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
       pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
@@ -847,13 +854,15 @@ int poro_pres_assemble_residual(poro_ctx *c, double dt, double *l2) {
 int poro_pres_assemble_jacobian(poro_ctx *c, double dt) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
+    // J = M/(M_b dt) + (k/mu) K depends on dt only (the reference recomputes it every pressure iteration): same dt, same matrix
+    if (c->jac_dt == dt) return 0;
     Timed tm(c, "pressure_jacobian");
     la_jacobian(c->stream, c->Jp.p, c->Mp.p, c->Kp.p, 1. / c->mat.biot_M / dt, c->mat.k_over_mu, c->Ap.nnz);
     la_csr_diag(c->stream, c->Ap, c->Jp.p, c->diag_J.p);
     exchange_add(c, c->diag_J.p, c->n_p, c->comm.part.plane_p);
     if (!c->dinv_J.p) c->dinv_J.alloc(c->n_p);
     la_reciprocal(c->stream, c->dinv_J.p, c->diag_J.p, c->n_p);
-    if (c->jac_dt != dt) c->ilu_J_valid = false;   // J = M/(M_b dt) + (k/mu) K changes with dt only
+    c->ilu_J_valid = false;
     c->jac_dt = dt;
     return 0;
   });
@@ -877,9 +886,10 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     if (opts->preconditioner == PORO_PREC_FDM) {
       build_fdm_p(c);
       const double kk[3] = {jk, jk, jk};
-      return pcg_host(c, c->n_p, owned(c, c->n_p, c->comm.part.plane_p), [&](const double *x, double *y) { apply(x, y, nullptr); },
-                      [&](const double *g, double *z) { fdm_precondition_p(c, ja, kk, g, z); },
-                      vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+      if (!c->wz_p.p) c->wz_p.alloc(c->n_p);
+      const std::function<void(const double *, double *)> P = [&](const double *g, double *z) { fdm_precondition_p(c, ja, kk, g, z); };
+      DiagVec dz; dz.full = c->dinv_J.p; dz.z = c->wz_p.p;
+      return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
     }
     DiagVec dv; dv.full = c->dinv_J.p;
     return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
@@ -944,9 +954,10 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
     if (opts->preconditioner == PORO_PREC_FDM) {
       build_fdm_p(c);
       const double kk[3] = {0, 0, 0};
-      return pcg_host(c, c->n_p, owned(c, c->n_p, c->comm.part.plane_p), [&](const double *x, double *y) { apply(x, y, nullptr); },
-                      [&](const double *g, double *z) { fdm_precondition_p(c, 1.0, kk, g, z); },
-                      vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+      if (!c->wz_p.p) c->wz_p.alloc(c->n_p);
+      const std::function<void(const double *, double *)> P = [&](const double *g, double *z) { fdm_precondition_p(c, 1.0, kk, g, z); };
+      DiagVec dz; dz.full = c->dinv_M.p; dz.z = c->wz_p.p;
+      return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
     }
     DiagVec dv; dv.full = c->dinv_M.p;
     return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);

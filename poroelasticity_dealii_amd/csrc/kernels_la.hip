@@ -199,7 +199,7 @@ __global__ void k_xpby(double *y, double a, double b, const double *x, int64_t n
 // ---- PCG (deal.II SolverCG structure: g = A x - b, d = -P^-1 g) ----------------------------------
 // INVERSE Jacobi diagonal (z = g * dinv: no fp64 division in the streaming kernels) either as a full vector or
 // dictionary-compressed: class byte per node (ncomp dofs each) + table[class][comp]
-struct DiagRef { const double *full; const uint8_t *cls; const double *tab; int ncomp; };
+struct DiagRef { const double *full; const uint8_t *cls; const double *tab; int ncomp; const double *z; };   // z != null: explicit z = P^-1 g computed by the caller
 // NC = components per node of the dictionary form (0: full vector); NC is a template parameter so that i / NC is a multiply
 template <int NC> __device__ inline double diag_at(const DiagRef &D, int64_t i) {
   if constexpr (NC == 0) return D.full[i];
@@ -217,7 +217,7 @@ template <int NC> __global__ void k_pcg_first_direction(double *d, const double 
   __shared__ double sh[4];
   double gg = 0, gz = 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double gi = g[i], z = prec ? gi * diag_at<NC>(D, i) : gi;
+    const double gi = g[i], z = D.z ? D.z[i] : prec ? gi * diag_at<NC>(D, i) : gi;
     d[i] = -z;
     if (i < n_owned) { gg += gi * gi; gz += gi * z; }
   }
@@ -277,7 +277,7 @@ template <int NC> __global__ void k_pcg_update_g_fused(PcgScalars *sc, int parit
   auto one = [&](int64_t i, double &gi) {
     const double Di = diag_at<NC>(D, i);
     if (Di == 0.0) { gi = 0.0; return; }
-    if (i < n_owned) { const double z = prec ? gi * Di : gi; gg += gi * gi; gz += gi * z; }
+    if (i < n_owned) { gg += gi * gi; if (!D.z) gz += gi * (prec ? gi * Di : gi); }   // explicit preconditioner: g.z follows in its own dot kernel once z = P^-1 g exists
   };
   // 16-byte accesses (two dofs per lane and step): the arrays are hipMalloc-aligned; an odd tail element goes to one thread
   const int64_t n2 = n >> 1;
@@ -318,13 +318,13 @@ template <int NC> __global__ void k_pcg_update_d_fused(PcgScalars *sc, int parit
     // which then stay resident in the 256 MB memory-side cache between the three kernels of an iteration (measured: -19 us / iteration)
     const double2 gv = g2[q]; double2 dv = d2[q], xv;
     xv.x = __builtin_nontemporal_load(&x[2 * q]); xv.y = __builtin_nontemporal_load(&x[2 * q + 1]);
-    const double z0 = prec ? gv.x * diag_at<NC>(D, 2 * q) : gv.x, z1 = prec ? gv.y * diag_at<NC>(D, 2 * q + 1) : gv.y;
+    const double z0 = D.z ? D.z[2 * q] : prec ? gv.x * diag_at<NC>(D, 2 * q) : gv.x, z1 = D.z ? D.z[2 * q + 1] : prec ? gv.y * diag_at<NC>(D, 2 * q + 1) : gv.y;
     xv.x = fma(alpha, dv.x, xv.x); xv.y = fma(alpha, dv.y, xv.y);
     dv.x = fma(beta, dv.x, -z0); dv.y = fma(beta, dv.y, -z1);
     __builtin_nontemporal_store(xv.x, &x[2 * q]); __builtin_nontemporal_store(xv.y, &x[2 * q + 1]); d2[q] = dv;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = n - 1; const double gi = g[i], z = prec ? gi * diag_at<NC>(D, i) : gi, di = d[i];
+    const int64_t i = n - 1; const double gi = g[i], z = D.z ? D.z[i] : prec ? gi * diag_at<NC>(D, i) : gi, di = d[i];
     x[i] = fma(alpha, di, x[i]); d[i] = fma(beta, di, -z);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->gh2[parity ^ 1] = gz; }
@@ -438,7 +438,7 @@ void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double 
 }
 void la_mask_zero(hipStream_t s, double *x, const uint8_t *mask, int64_t n) { if (n) hipLaunchKernelGGL(k_mask_zero, grid_for(n), kBlock, 0, s, x, mask, n); }
 void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVec &dv, int prec, int64_t n, int64_t n_owned, double *partials) {
-  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp};
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, dv.z};
   switch (diag_nc(dv, n)) {
     case 2: hipLaunchKernelGGL(k_pcg_first_direction<2>, reduce_grid(n), kBlock, 0, s, d, g, D, prec, n, n_owned, partials); break;
     case 3: hipLaunchKernelGGL(k_pcg_first_direction<3>, reduce_grid(n), kBlock, 0, s, d, g, D, prec, n, n_owned, partials); break;
@@ -456,7 +456,7 @@ void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red, double 
 }
 void pcg_update_g_fused(hipStream_t s, PcgScalars *sc, int parity, double *g, const double *h, const DiagVec &dv, int prec, int64_t n, int64_t n_owned,
                         const double *partials_dh, const double *red, double *partials_out) {
-  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp};
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, dv.z};
   switch (diag_nc(dv, n)) {
     case 2: hipLaunchKernelGGL(k_pcg_update_g_fused<2>, reduce_grid(n), kBlock, 0, s, sc, parity, g, h, D, prec, n, n_owned, partials_dh, red, partials_out); break;
     case 3: hipLaunchKernelGGL(k_pcg_update_g_fused<3>, reduce_grid(n), kBlock, 0, s, sc, parity, g, h, D, prec, n, n_owned, partials_dh, red, partials_out); break;
@@ -465,7 +465,7 @@ void pcg_update_g_fused(hipStream_t s, PcgScalars *sc, int parity, double *g, co
 }
 void pcg_update_d_fused(hipStream_t s, PcgScalars *sc, int parity, int it, double *x, double *d, const double *g, const DiagVec &dv, int prec, int64_t n,
                         const double *partials_in, const double *red) {
-  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp};
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, dv.z};
   switch (diag_nc(dv, n)) {
     case 2: hipLaunchKernelGGL(k_pcg_update_d_fused<2>, reduce_grid(n), kBlock, 0, s, sc, parity, it, x, d, g, D, prec, n, partials_in, red); break;
     case 3: hipLaunchKernelGGL(k_pcg_update_d_fused<3>, reduce_grid(n), kBlock, 0, s, sc, parity, it, x, d, g, D, prec, n, partials_in, red); break;

@@ -274,7 +274,8 @@ template <int dim> class PoroElasticProblem {
         pressure_error = pressure_solver.residual_l2;      // :364
         inner = pressure_error;
         if (pressure_error < rc.pressure_tol) break;       // :366-371
-        pressure_solver.assemble_jacobian(rc.time_step); work.jacobian_p++;   // :377
+        pressure_solver.assemble_jacobian(rc.time_step);                       // :377
+        if (rc.time_step != jacobian_dt) { work.jacobian_p++; jacobian_dt = rc.time_step; }   // the library re-forms J only when dt changed
         pressure_solver.solve();                           // :378
         pcg += pressure_solver.last.iterations; work.cg_p += pressure_solver.last.iterations; work.apply_p += pressure_solver.last.operator_applications;
         pressure_solver.solution += pressure_solver.solution_update;   // :379
@@ -313,7 +314,7 @@ template <int dim> class PoroElasticProblem {
   void normal_strains() {
     get_normal_strain_components(); work.proj_rhs++;
   }
-  bool first_assembly = true; int time_step_number = 0;
+  bool first_assembly = true; int time_step_number = 0; double jacobian_dt = -1;
   const ProblemData *pd;
   static poro_ctx *make_ctx(ProblemData &P, int device, int operator_mode) {
     poro_ctx *c = nullptr;
