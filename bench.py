@@ -104,12 +104,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--degree", type=int, default=2)
-    ap.add_argument("--n", type=int, default=72, help="cells per direction per GPU")
+    ap.add_argument("--n", "--cells", dest="n", type=int, default=72, help="cells per direction per GPU (use --cells under torch.distributed.run, whose own parser treats --n as an abbreviation)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--rel-tol", type=float, default=1e-10, help="displacement CG: recursive residual <= max(1e-12, rel_tol*||b||) (SURVEY §7 hard parts)")
     ap.add_argument("--max-iter", type=int, default=50000)
     ap.add_argument("--cpu-n", type=int, default=9, help="cells per direction of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: all ranks use device 0 and exchange through gloo (host-staged callbacks) instead of RCCL")
     ap.add_argument("--trace-out", default=None, help="write the per-step record (SURVEY 8d config 5: FSS / pressure / Krylov iteration counts, wall-clock) to this JSON file")
     args = ap.parse_args()
 
@@ -122,6 +123,8 @@ def main():
         import torch
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         if world > 1:
             import torch.distributed as dist
@@ -136,7 +139,19 @@ def main():
     P = pk.Problem.box(dim, n, size, deg, material(), BC_3D[:2 * dim], (), rank, world)
     R = pk.Runner(P, device=local_rank, operator_mode=pk.OP_MATRIX_FREE, p_init=INPUT["p_init"], dt=INPUT["dt"], abs_u=1e-12, rel_u=args.rel_tol, max_it=args.max_iter)
     G = R.ctx
-    if world > 1:
+    if world > 1 and args.share_gpu:
+        import numpy as np
+
+        def _allreduce(buf):
+            t = torch.from_numpy(buf.copy()); dist.all_reduce(t); buf[:] = t.numpy()
+
+        def _sendrecv(send, recv, peer):
+            ts, tr = torch.from_numpy(np.array(send, copy=True)), torch.empty(len(recv), dtype=torch.float64)
+            for r in [dist.isend(ts, peer), dist.irecv(tr, peer)]:
+                r.wait()
+            recv[:] = tr.numpy()
+        G.comm_callbacks(_allreduce, _sendrecv)
+    elif world > 1:
         ids = [pk.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         G.comm_rccl(ids[0])
