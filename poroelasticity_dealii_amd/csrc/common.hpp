@@ -198,7 +198,7 @@ void asm_proj_rhs(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t
 
 // ---- kernels_mf.hip -----------------------------------------------------------------------------
 struct MfArgs { int dim, k_u; BoxDev box; const double *Ke; const uint8_t *mask; const double *diag_local; double lam, G; int mask_anywhere; const uint8_t *nodemask; const int32_t *dirichlet_dofs; int64_t n_dirichlet; };
-void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained);
+void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, double *dot_partials = nullptr);
 void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
 // y = (a M + kappa K) x for the Q1 pressure space of a uniform box (constant-coefficient 3^dim-point stencil)
 void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double kappa, const double *x, double *y);

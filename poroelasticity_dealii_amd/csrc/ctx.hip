@@ -219,7 +219,7 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
     fused = dot_partials != nullptr;
   } else {
     Timed tm(c, mode == PORO_OP_MATRIX_FREE ? "apply_u_matrix_free" : "apply_u_csr");
-    if (mode == PORO_OP_MATRIX_FREE) mf_apply(c->stream, mf_args(c), x, y, true);
+    if (mode == PORO_OP_MATRIX_FREE) { mf_apply(c->stream, mf_args(c), x, y, true, dot_partials); fused = dot_partials != nullptr; }
     else la_csr_spmv(c->stream, c->Au, c->Au_val.p, x, y);
   }
   exchange_add(c, y, c->n_u, c->comm.part.plane_u);

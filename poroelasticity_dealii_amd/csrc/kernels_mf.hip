@@ -41,11 +41,15 @@ __device__ inline int64_t xcd_tile(int64_t bid, int64_t n) {
 template <int DIM, int K, bool DIAG_ONLY>
 __global__ void __launch_bounds__((Cfg<DIM, K>::NW * 64))
 k_mf_apply(MfGeom g, const double *__restrict__ Ke, const double *__restrict__ x, double *__restrict__ y, const uint8_t *__restrict__ mask,
-           const double *__restrict__ diag_local, int constrained) {
+           const double *__restrict__ diag_local, int constrained, double *__restrict__ dot_partials) {
   using C = Cfg<DIM, K>;
   __shared__ double sx[DIAG_ONLY ? 1 : C::LDS_NODES * DIM];   // [comp][node] (SoA: conflict-light ds_read_b64)
+  __shared__ double sdot[C::NW];
   const int tid = threadIdx.x;
-  const int64_t tile = xcd_tile(blockIdx.x, g.n_tiles);
+  double dot_acc = 0.0;                                        // x.y over this workgroup's tiles (fused d.Ad of PCG)
+  // one tile per workgroup, except when the fused dot product limits the grid to the number of partial slots
+  for (int64_t tile_i = blockIdx.x; tile_i < g.n_tiles; tile_i += gridDim.x) {
+  const int64_t tile = gridDim.x == g.n_tiles ? xcd_tile(tile_i, g.n_tiles) : tile_i;
   int t[3];
   t[0] = (int)(tile % g.nt[0]); t[1] = (int)((tile / g.nt[0]) % g.nt[1]); t[2] = (int)(tile / ((int64_t)g.nt[0] * g.nt[1]));
   const int org[3] = {t[0] * C::T0, t[1] * C::T1, DIM == 3 ? t[2] * C::T2 : 0};
@@ -124,14 +128,30 @@ k_mf_apply(MfGeom g, const double *__restrict__ Ke, const double *__restrict__ x
           }
         }
       }
-  if (!in_range) return;
-  const int64_t nodeid = ((int64_t)node[2] * g.nn[1] + node[1]) * g.nn[0] + node[0];
+  if (in_range) {
+    const int64_t nodeid = ((int64_t)node[2] * g.nn[1] + node[1]) * g.nn[0] + node[0];
 #pragma unroll
-  for (int a = 0; a < DIM; ++a) {
-    const int64_t dof = nodeid * DIM + a;
-    double v = acc[a];
-    if constexpr (!DIAG_ONLY) { if (constrained && mask[dof]) v = diag_local[dof] * x[dof]; }
-    y[dof] = v;
+    for (int a = 0; a < DIM; ++a) {
+      const int64_t dof = nodeid * DIM + a;
+      double v = acc[a];
+      if constexpr (!DIAG_ONLY) {
+        const double xv = x[dof];
+        if (constrained && mask[dof]) v = diag_local[dof] * xv;
+        dot_acc = fma(xv, v, dot_acc);
+      }
+      y[dof] = v;
+    }
+  }
+  if (tile_i + gridDim.x < g.n_tiles) __syncthreads();          // the next tile refills sx
+  }
+  if constexpr (!DIAG_ONLY) {
+    if (dot_partials) {                                          // fixed shuffle tree, waves summed in index order: bitwise reproducible
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_xor(dot_acc, off, 64);
+      if ((tid & 63) == 0) sdot[tid >> 6] = dot_acc;
+      __syncthreads();
+      if (tid == 0) { double tsum = 0; for (int q = 0; q < C::NW; ++q) tsum += sdot[q]; dot_partials[blockIdx.x] = tsum; }
+    }
   }
 }
 
@@ -147,18 +167,19 @@ template <int DIM, int K> MfGeom make_geom(const BoxDev &box) {
   return g;
 }
 
-template <int DIM, int K> void launch(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, bool diag_only) {
+template <int DIM, int K> void launch(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, bool diag_only, double *dot_partials) {
   using C = Cfg<DIM, K>;
   const MfGeom g = make_geom<DIM, K>(a.box);
-  if (diag_only) hipLaunchKernelGGL((k_mf_apply<DIM, K, true>), (unsigned)g.n_tiles, C::NW * 64, 0, s, g, a.Ke, x, y, a.mask, a.diag_local, 0);
-  else hipLaunchKernelGGL((k_mf_apply<DIM, K, false>), (unsigned)g.n_tiles, C::NW * 64, 0, s, g, a.Ke, x, y, a.mask, a.diag_local, constrained ? 1 : 0);
+  const unsigned grid = (unsigned)(dot_partials ? std::min<int64_t>(g.n_tiles, kMaxPartials) : g.n_tiles);   // one partial slot per workgroup
+  if (diag_only) hipLaunchKernelGGL((k_mf_apply<DIM, K, true>), grid, C::NW * 64, 0, s, g, a.Ke, x, y, a.mask, a.diag_local, 0, (double *)nullptr);
+  else hipLaunchKernelGGL((k_mf_apply<DIM, K, false>), grid, C::NW * 64, 0, s, g, a.Ke, x, y, a.mask, a.diag_local, constrained ? 1 : 0, dot_partials);
 }
 
-void dispatch(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, bool diag_only) {
-  if (a.dim == 2 && a.k_u == 1) launch<2, 1>(s, a, x, y, constrained, diag_only);
-  else if (a.dim == 2 && a.k_u == 2) launch<2, 2>(s, a, x, y, constrained, diag_only);
-  else if (a.dim == 3 && a.k_u == 1) launch<3, 1>(s, a, x, y, constrained, diag_only);
-  else if (a.dim == 3 && a.k_u == 2) launch<3, 2>(s, a, x, y, constrained, diag_only);
+void dispatch(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, bool diag_only, double *dot_partials = nullptr) {
+  if (a.dim == 2 && a.k_u == 1) launch<2, 1>(s, a, x, y, constrained, diag_only, dot_partials);
+  else if (a.dim == 2 && a.k_u == 2) launch<2, 2>(s, a, x, y, constrained, diag_only, dot_partials);
+  else if (a.dim == 3 && a.k_u == 1) launch<3, 1>(s, a, x, y, constrained, diag_only, dot_partials);
+  else if (a.dim == 3 && a.k_u == 2) launch<3, 2>(s, a, x, y, constrained, diag_only, dot_partials);
   else throw Error("mf_apply: unsupported dim / degree");
 }
 
@@ -185,7 +206,8 @@ void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double
   else hipLaunchKernelGGL(k_p_stencil<3>, grid, 256, 0, s, n0, n1, n2, box.h[0], box.h[1], box.h[2], a, kappa, x, y);
 }
 
-void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained) { dispatch(s, a, x, y, constrained, false); }
+// dot_partials (optional, kMaxPartials slots zeroed once by the caller): per-workgroup partial sums of x.y over all local rows
+void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, double *dot_partials) { dispatch(s, a, x, y, constrained, false, dot_partials); }
 void mf_diag(hipStream_t s, const MfArgs &a, double *diag) { dispatch(s, a, nullptr, diag, false, true); }
 
 }  // namespace poro
