@@ -145,6 +145,7 @@ void la_fill(hipStream_t s, double *x, double v, int64_t n);
 void la_copy(hipStream_t s, double *y, const double *x, int64_t n);
 void la_axpy(hipStream_t s, double *y, double a, const double *x, int64_t n);
 void la_add_range(hipStream_t s, double *y, const double *x, int64_t n);
+void la_add_two_ranges(hipStream_t s, double *y0, const double *x0, double *y1, const double *x1, int64_t n);
 // partials-based reductions; results land in red[slot..] after la_reduce_finish
 void la_dot_partials(hipStream_t s, const double *a, const double *b, int64_t n, double *partials /*[kMaxPartials]*/);
 void la_norm_partials(hipStream_t s, const double *a, int64_t n, double *partials_l2, double *partials_inf);

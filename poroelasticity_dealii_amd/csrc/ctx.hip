@@ -160,8 +160,7 @@ void exchange_add(poro_ctx *c, double *v, int64_t n, int64_t plane) {
     if (cm.part.has_upper) one(v + n - plane, cm.recv_hi.p, cm.part.rank + 1);
     if (cm.part.has_lower) one(v, cm.recv_lo.p, cm.part.rank - 1);
   } else throw Error("partitioned context without a communicator (call poro_ctx_comm_init_* first)");
-  if (cm.part.has_upper) la_add_range(c->stream, v + n - plane, cm.recv_hi.p, plane);
-  if (cm.part.has_lower) la_add_range(c->stream, v, cm.recv_lo.p, plane);
+  la_add_two_ranges(c->stream, cm.part.has_upper ? v + n - plane : nullptr, cm.recv_hi.p, cm.part.has_lower ? v : nullptr, cm.recv_lo.p, plane);
 }
 void allreduce_sum(poro_ctx *c, double *dev, int n) {
   Comm &cm = c->comm;

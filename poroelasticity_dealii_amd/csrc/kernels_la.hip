@@ -346,6 +346,13 @@ void la_fill(hipStream_t s, double *x, double v, int64_t n) { if (n) hipLaunchKe
 void la_copy(hipStream_t s, double *y, const double *x, int64_t n) { if (n && y != x) PORO_HIP(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, s)); }
 void la_axpy(hipStream_t s, double *y, double a, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_axpy, grid_for(n), kBlock, 0, s, y, a, x, n); }
 void la_add_range(hipStream_t s, double *y, const double *x, int64_t n) { la_axpy(s, y, 1.0, x, n); }
+// both interface planes of a slab in one launch (either pair may be null)
+__global__ void k_add_two_ranges(double *y0, const double *x0, double *y1, const double *x1, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) { if (y0) y0[i] += x0[i]; if (y1) y1[i] += x1[i]; }
+}
+void la_add_two_ranges(hipStream_t s, double *y0, const double *x0, double *y1, const double *x1, int64_t n) {
+  if (n && (y0 || y1)) hipLaunchKernelGGL(k_add_two_ranges, grid_for(n), kBlock, 0, s, y0, x0, y1, x1, n);
+}
 void la_dot_partials(hipStream_t s, const double *a, const double *b, int64_t n, double *partials) {
   hipLaunchKernelGGL(k_dot, reduce_grid(n), kBlock, 0, s, a, b, n, partials);
 }
