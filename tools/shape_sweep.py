@@ -1,0 +1,34 @@
+"""Robustness sweep: context creation (which self-checks the structured kernels against the per-cell / gather kernels) and one operator application
+for many ragged box shapes, both degrees."""
+import sys, os, itertools
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))   # (tests/common.py takes the material constants from the oracle)
+import numpy as np
+import poroelasticity_dealii_amd as pk
+from common import box_problem
+
+shapes3 = [(1, 1, 1), (1, 2, 3), (2, 2, 2), (3, 5, 7), (5, 3, 2), (7, 7, 7), (10, 13, 4), (17, 3, 9), (31, 6, 5), (33, 2, 2), (2, 33, 3), (2, 3, 41), (29, 31, 5), (30, 15, 16)]
+shapes2 = [(1, 1), (2, 3), (7, 5), (16, 17), (33, 9), (64, 3), (5, 100)]
+bad = 0
+for deg in (1, 2):
+    for n in shapes3 + shapes2:
+        dim = len(n)
+        P = box_problem(dim, n, deg)
+        try:
+            G = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+            G.fill(pk.VEC_P, 1e7); G.disp_assemble_system(True)
+            C = pk.Context(P, 0, pk.OP_CSR); C.fill(pk.VEC_P, 1e7); C.disp_assemble_system(True)
+            x = np.sin(0.11 * np.arange(G.n_u))
+            y, y0 = G.apply(pk.MAT_A_U, x), C.apply(pk.MAT_A_U, x)
+            err = np.abs(y - y0).max() / np.abs(y0).max()
+            rc, info = G.disp_solve(abs_tol=1e-12, rel_tol=1e-10, max_iter=20000)
+            rc2, info2 = C.disp_solve(abs_tol=1e-12, rel_tol=1e-10, max_iter=20000)
+            du = np.linalg.norm(G.get(pk.VEC_U) - C.get(pk.VEC_U)) / max(np.linalg.norm(C.get(pk.VEC_U)), 1e-300)
+            ok = err < 1e-12 and rc == 0 and rc2 == 0 and du < 1e-7
+            bad += not ok
+            print(f"Q{deg} {n}: apply err {err:.1e}, solve rc {rc}/{rc2} its {info.iterations}/{info2.iterations}, du {du:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+            G.close(); C.close()
+        finally:
+            P.close()
+print("failures:", bad)
+sys.exit(1 if bad else 0)
