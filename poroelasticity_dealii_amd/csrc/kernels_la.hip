@@ -104,7 +104,16 @@ template <int L> __global__ void k_spmv(int64_t n, const int64_t *__restrict__ r
   if (row >= n) return;   // whole L-groups leave together (kBlock % L == 0)
   const int64_t b = rp[row], e = rp[row + 1];
   double s = 0;
-  for (int64_t j = b + lane; j < e; j += L) s += val[j] * x[col[j]];
+  // 4 (value, column) pairs per lane are requested before the first gather of x is issued: two dependent memory latencies per trip
+  // instead of two per element (a Q2 hex row has 189 entries = one trip of a 64-lane group)
+  constexpr int U = 4;
+  for (int64_t j0 = b + lane; j0 < e; j0 += (int64_t)L * U) {
+    double v[U]; int32_t c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int64_t j = j0 + (int64_t)u * L; const bool ok = j < e; v[u] = ok ? val[j] : 0.0; c[u] = col[ok ? j : b]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) s = fma(v[u], x[c[u]], s);
+  }
 #pragma unroll
   for (int off = L / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, L);
   if (lane == 0) y[row] = s;
@@ -117,7 +126,14 @@ template <int L> __global__ void k_residual(int64_t n, const int64_t *__restrict
   if (row >= n) return;
   const int64_t b = rp[row], e = rp[row + 1];
   double s1 = 0, s2 = 0;
-  for (int64_t j = b + lane; j < e; j += L) { const int32_t c = col[j]; s1 += M[j] * t[c]; s2 += K[j] * p[c]; }
+  constexpr int U = 4;                                    // as k_spmv: the loads of a trip are issued before its gathers
+  for (int64_t j0 = b + lane; j0 < e; j0 += (int64_t)L * U) {
+    double vm[U], vk[U]; int32_t c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int64_t j = j0 + (int64_t)u * L; const bool ok = j < e; vm[u] = ok ? M[j] : 0.0; vk[u] = ok ? K[j] : 0.0; c[u] = col[ok ? j : b]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { s1 = fma(vm[u], t[c[u]], s1); s2 = fma(vk[u], p[c[u]], s2); }
+  }
 #pragma unroll
   for (int off = L / 2; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, L); s2 += __shfl_xor(s2, off, L); }
   // same association as the reference: residual = M t; tmp = (K p) * kappa; residual += tmp; += source; *= -1
