@@ -132,6 +132,7 @@ struct poro_ctx {
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
   int interleaved_u = 0;
+  int pcg_hint_u[2] = {0, 0};   // iterations of the last two displacement solves (batch scheduling of the next one)
   int n_cus = 256; int mf_variant = 1 /* 0 element-matrix gather, 1 sum-factorised (where supported) */; int mask_anywhere = 0;
   // timing
   bool timing = false; std::map<std::string, poro::Timer> timers;
@@ -214,7 +215,8 @@ void fdm_window(hipStream_t s, double *dst, const double *src, bool to_block, in
 void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t n_outer, const double *in, double *out, const FdmScale *scale);
 void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], const double *g, double *z, double *t1, double *t2);
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
-int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);   // returns the workgroup count (= partial slots used)
+int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+               const PcgScalars *pcg = nullptr /* launch becomes a no-op once pcg->done / finishing is set */);   // returns the workgroup count (= partial slots used)
 void kron_fix_constrained(hipStream_t s, const MfArgs &a, const double *x, double *y, double *dot_partials, int slot_base);
 
 }  // namespace poro

@@ -204,15 +204,15 @@ bool is_u_vec(int which) { return which == PORO_VEC_U || which == PORO_VEC_RHS_U
 
 // y = A_u x (+ interface exchange).  dot_partials != null asks for the block partials of x.y; returns true when they were produced
 // by the operator kernel itself (fused), false when the caller still has to launch the dot kernel.
-bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr, bool fix_rows = true) {
+bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr, bool fix_rows = true, const PcgScalars *pcg_state = nullptr) {
   bool fused = false;
   if (mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
     int slots;
     if (c->timing) {   // events attached to the dispatch itself: the kernel's own duration, without the gaps to its neighbours in the stream
       Timer &t = c->timers["apply_u_matrix_free"]; hipEvent_t e0 = event_get(), e1 = event_get();
-      slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials, e0, e1);
+      slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials, e0, e1, pcg_state);
       t.pending.emplace_back(e0, e1); t.launches++;
-    } else slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials);
+    } else slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials, nullptr, nullptr, pcg_state);
     // inside PCG the Dirichlet rows are inert (zero residual and direction), so what the structured kernel leaves there is never read
     if (fix_rows) { Timed tm(c, "apply_u_dirichlet_rows"); kron_fix_constrained(c->stream, mf_args(c), x, y, dot_partials, slots); }
     fused = dot_partials != nullptr;
@@ -232,7 +232,7 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
 // diag.z between the two update kernels; the scalars stay on the device exactly as in the Jacobi case.
 int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
         const DiagVec &diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info,
-        const std::function<void(const double *, double *)> *precond = nullptr) {
+        const std::function<void(const double *, double *)> *precond = nullptr, int *its_hint = nullptr) {
   hipStream_t s = c->stream;
   const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
   double *zbuf = const_cast<double *>(diag.z);
@@ -255,6 +255,11 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   PORO_HIP(hipMemsetAsync(part_dh, 0, kMaxPartials * sizeof(double), s));
   PcgScalars hs{};
   int batch = precond ? 1 : 4, it = 0;   // an explicit preconditioner is expensive and strong: poll after every iteration at first
+  // expected iteration count: linear extrapolation of the last two solves of this system (a transient's warm-started counts drift steadily)
+  int expect = 0;
+  if (its_hint && its_hint[0] > 0) { expect = its_hint[1] > 0 ? 2 * its_hint[0] - its_hint[1] : its_hint[0]; expect = std::max(expect, its_hint[0] / 2); }
+  auto next_batch = [&](int done_its) { const int left = expect - 6 - done_its; return left >= 4 ? std::min(32, left) : 3; };
+  if (expect > 0) batch = next_batch(0);
   while (true) {
     PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
     if (hs.done || hs.finishing) break;
@@ -270,11 +275,18 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
       if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
       pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
-    if (batch < 32) batch *= 2;
+    // iterations are enqueued in batches between polls of the device-side state.  Launches behind the finishing iteration are no-ops;
+    // a warm-started solve takes about as many iterations as the previous one, so with a hint the big batches stop a few iterations
+    // short of it and the tail is polled in pairs (few no-op launches, few host round trips)
+    if (expect > 0) batch = next_batch(it);
+    else if (batch < 32) batch *= 2;
   }
+  if (its_hint) { its_hint[1] = its_hint[0]; its_hint[0] = hs.it; }
   PORO_HIP(hipEventRecord(e1, s)); PORO_HIP(hipEventSynchronize(e1));
   float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (info) { info->iterations = hs.it; info->converged = hs.converged; info->initial_residual = hs.res0; info->final_residual = hs.res; info->seconds = ms * 1e-3; info->operator_applications = applies; }
+  if (info) { info->iterations = hs.it; info->converged = hs.converged; info->initial_residual = hs.res0; info->final_residual = hs.res; info->seconds = ms * 1e-3;
+              info->operator_applications = hs.it + 1;   // initial residual + one per iteration (launches enqueued behind the finishing iteration are no-ops and are not counted)
+              (void)applies; }
   return hs.converged ? 0 : 1;
 }
 
@@ -821,10 +833,10 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       PORO_HIP(hipStreamSynchronize(c->stream));
       return rc;
     }
-    auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp, false); };
+    auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp, false, dp ? c->scal.p : nullptr); };
     DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim; dv.inert = c->dir_mask.p;
     if (c->diag_u_cls.p) { dv.cls = c->diag_u_cls.p; dv.tab = c->diag_u_tab.p; }
-    const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dv, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
+    const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dv, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, nullptr, c->pcg_hint_u);
     la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);   // constraints.distribute (:306)
     PORO_HIP(hipStreamSynchronize(c->stream));
     return rc;

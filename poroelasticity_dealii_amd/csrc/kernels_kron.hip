@@ -46,6 +46,7 @@ struct KronArgs {
   KronConsts k;
   const uint8_t *nodemask; int constrained, mask_anywhere;
   double *dot_partials;   // optional: per-workgroup partial of x.y over the free rows (x is zero on the Dirichlet columns after masking)
+  const PcgScalars *pcg;  // optional: inside PCG the launch is a no-op once the solve has finished (the host enqueues iterations in batches)
 };
 
 __device__ inline int64_t xcd_remap(int64_t bid, int64_t n) {
@@ -264,6 +265,7 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
 __global__ void __launch_bounds__(1024)
 k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];                            // [2 buffers][9 fields][1024 nodes of the tile plane]
+  if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;  // uniform over the grid: written by the previous launches only
   const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);  // workgroup-uniform: either tile shape, never both
   if (tile < a.nA) kron_tile<64>(a, x, y, L, 60 * (tile / (a.nzc * a.nty64)) - 2, (tile / a.nzc) % a.nty64, tile % a.nzc);
   else { const int t = tile - a.nA; kron_tile<32>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
@@ -419,6 +421,7 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
 __global__ void __launch_bounds__(1024)
 k_kron3_q1(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];
+  if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
   const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
   if (tile < a.nA) kron_tile_q1<64>(a, x, y, L, 62 * (tile / (a.nzc * a.nty64)) - 1, (tile / a.nzc) % a.nty64, tile % a.nzc);
   else { const int t = tile - a.nA; kron_tile_q1<32>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
@@ -462,7 +465,7 @@ void check_q2_element_matrices() {
 
 bool kron_supported(int dim, int k_u) { return dim == 3 && (k_u == 1 || k_u == 2); }
 
-int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1) {
+int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1, const PcgScalars *pcg) {
   static bool checked = false;
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
@@ -502,7 +505,7 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   }
   const int nblk = a.nblocks;
   if (dot_partials && nblk > kMaxPartials / 2) throw Error("kron_apply: too many workgroups for the fused dot product");
-  a.dot_partials = dot_partials;
+  a.dot_partials = dot_partials; a.pcg = pcg;
   // ev0 / ev1 (optional): timestamps at the start / end of THIS dispatch, so the measured time is the kernel's own duration
   if (ku == 2) hipExtLaunchKernelGGL(k_kron3_q2, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
   else hipExtLaunchKernelGGL(k_kron3_q1, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
