@@ -16,7 +16,9 @@
 //   x: lanes are consecutive nodes; contributions to the nodes at +-1, +-2 travel by wave shuffles (scatter form).
 // Rows are dealt to waves so that the four waves sharing a SIMD carry equal work (vertex rows cost more than mid rows,
 // halo rows only run the z-stage).  Out-of-domain nodes are loaded as zeros, so only the centre coefficients know about
-// the domain boundary.  No atomics; results are bitwise reproducible.  Dirichlet rows / columns handled as in k_mf_apply.
+// the domain boundary.  No atomics; results are bitwise reproducible.  Dirichlet columns are masked as planes enter the window; the
+// Dirichlet ROWS hold the unconstrained row sums: PCG never reads them (inert dofs), poro_apply_operator finishes them with
+// k_kron_fix_constrained.
 #include "common.hpp"
 #include <hip/hip_ext.h>
 
@@ -185,7 +187,7 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
     };
     const double (&xc)[3] = oddz ? W3 : W2;            // this plane's (masked) input values, for the fused x.y
     const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
-    auto emit = [&](int c, double v) { if (out) { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); } };   // constrained rows are rewritten by k_kron_fix_constrained
+    auto emit = [&](int c, double v) { if (out) { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); } };   // Dirichlet rows: see the header
 
     if (!has_w) {
       if (halo_wave) return;
