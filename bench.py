@@ -7,6 +7,8 @@ One "step" = one time step of the reference's loop (PoroelasticityFSS.h:328-407)
 projection (RHS assembly + dim CG solves), residual check.  A DoF-update is one entry of a vector
 produced by an operator application y = A x or by an assembly pass; `value` = DoF-updates of the K timed steps
 (all ranks) / wall time of those steps, INCLUDING the Krylov vector work, reductions and host control.
+Only useful work is counted: (iterations + 1) operator applications per CG solve (launches the batched PCG loop
+enqueues behind the finishing iteration are no-ops), the Jacobian only when dt changed.
 
 Workload: 3D Q2/Q1 uniform box, 72^3 cells per GPU (N_u = 9 145 875 at 1 GPU: BASELINE config "3D Q2/Q1 ~10M DoF");
 weak scaling: rank r owns a z-slab of 72 cell layers of a 72 x 72 x 72N box (edge 10 x 10 x 10N, same h).
