@@ -465,3 +465,24 @@ def test_ragged_box_shapes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "shape_sweep.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "failures: 0" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_transient_of_ten_steps_tracks_the_oracle():
+    """BASELINE config 5 in miniature: 10 time steps (warm starts, pressure history, the fast-diagonalised pressure / projection solves, the
+    structured right-hand sides) against the oracle's restatement of the same loop: identical FSS / pressure iteration counts per step
+    and the same pressure and displacement at the end."""
+    P = box_problem(3, 4, 2, mat=host_material())
+    O = oracle_py.Oracle(P)
+    try:
+        t0, _ = O.run(10, REF["p_init"], REF["dt"], max_it=2000)
+        assert O.noconvergence_count() == 0
+        t1, G = pk.run_problem(P, 10, REF["p_init"], REF["dt"], operator_mode=pk.OP_MATRIX_FREE, max_it=5000)
+        try:
+            assert t1.shape == t0.shape and np.array_equal(t1[:, :3], t0[:, :3])
+            assert np.allclose(t1[:, 4], t0[:, 4], rtol=1e-10)                       # |p|_inf after every step
+            assert rel2(G.get(pk.VEC_P), O.get(pk.VEC_P)) <= 1e-10
+            assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-8
+        finally:
+            G.close()
+    finally:
+        O.close(); P.close()
