@@ -207,8 +207,7 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     # tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py); null when no profile is committed
-    kron = dim == 3
-    kernel_label = ("k_kron3_q%d (matrix-free y = A_u x, sum-factorised)" % deg) if kron else ("k_mf_apply<%d,%d> (matrix-free y = A_u x, element-matrix gather)" % (dim, deg))
+    kernel_label = ("k_kron3_q%d" % deg if dim == 3 else "k_kron2<%d>" % deg) + " (matrix-free y = A_u x, sum-factorised)"
     traffic = None
     try:
         # committed PMC passes of tools/bench_ops.py on the two BASELINE meshes of the structured kernels (config 4: 72^3 Q2, config 3: 99^3 Q1)

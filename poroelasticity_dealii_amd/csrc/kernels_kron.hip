@@ -429,6 +429,85 @@ k_kron3_q1(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   else { const int t = tile - a.nA; kron_tile_q1<32>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
 }
 
+// ---- 2D (Q2 and Q1): A_xx = (l+2G) Kx (x) My + G Mx (x) Ky,  A_yy = G Kx (x) My + (l+2G) Mx (x) Ky,
+//      A_xy = l Cx (x) Cy^T + G Cx^T (x) Cy,  A_yx = A_xy^T.   No march: one 64 x 16 tile per trip, the two components of the tile go through
+// LDS for the y-stage (one row per wave), the x-stage is the same scatter-by-DPP as in 3D.  A workgroup loops over tiles when the fused
+// dot product limits the grid to the number of partial slots.
+template <int KU> __global__ void __launch_bounds__(1024)
+k_kron2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
+  constexpr int H = KU == 2 ? 2 : 1, VX = 64 - 2 * H, VY = 16 - 2 * H;
+  __shared__ double L[2 * 16 * 64];
+  __shared__ double sdot[16];
+  if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
+  const int tid = threadIdx.x, r = __builtin_amdgcn_readfirstlane(tid >> 6), lx = tid & 63;
+  const int NX = a.nn[0], NY = a.nn[1];
+  const int ntx = (NX + VX - 1) / VX, ntiles = a.nblocks;
+  const KronConsts &K = a.k;
+  const bool halo_wave = r < H || r > 15 - H;
+  double dot_acc = 0.0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int X0 = VX * (tile % ntx) - H, Y0 = VY * (tile / ntx) - H;
+    const int i = X0 + lx, j = Y0 + r;
+    const bool vn = i >= 0 && i < NX && j >= 0 && j < NY;
+    const bool out = vn && lx >= H && lx <= 63 - H && !halo_wave;
+    double u[2] = {0.0, 0.0};
+    const int64_t node = (int64_t)j * NX + i;
+    if (vn) {
+      u[0] = x[node * 2]; u[1] = x[node * 2 + 1];
+      if (a.constrained && (a.mask_anywhere || i == 0 || i == NX - 1 || j == 0 || j == NY - 1)) { const unsigned m = a.nodemask[node]; if (m & 1u) u[0] = 0.0; if (m & 2u) u[1] = 0.0; }
+    }
+    L[r * 64 + lx] = u[0]; L[(16 + r) * 64 + lx] = u[1];
+    __syncthreads();
+    if (!halo_wave) {
+      const double mLx = i > 0 ? 1.0 : 0.0, mRx = i < NX - 1 ? 1.0 : 0.0, mLy = j > 0 ? 1.0 : 0.0, mRy = j < NY - 1 ? 1.0 : 0.0;
+      // centre coefficients and band forms of the integer 1D matrices (see the 3D kernels): vertex / mid parity only exists for Q2
+      const bool even_i = (lx & 1) == 0, odd_row = KU == 2 && (r & 1) != 0;
+      double cMx, cKx, cDx, cMy, cKy, cDy, pe = 0.0;
+      if constexpr (KU == 2) {
+        pe = even_i ? 1.0 : 0.0;
+        cMx = even_i ? 4.0 * (mLx + mRx) : 16.0; cKx = even_i ? 7.0 * (mLx + mRx) : 16.0; cDx = even_i ? 3.0 * (mLx - mRx) : 0.0;
+        cMy = odd_row ? 16.0 : 4.0 * (mLy + mRy); cKy = odd_row ? 16.0 : 7.0 * (mLy + mRy); cDy = odd_row ? 0.0 : 3.0 * (mLy - mRy);
+      } else { cMx = 2.0 * (mLx + mRx); cKx = mLx + mRx; cDx = mLx - mRx; cMy = 2.0 * (mLy + mRy); cKy = mLy + mRy; cDy = mLy - mRy; }
+      double My[2], Ky[2], Oy[2], Dy[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double *col = L + (c * 16 + r) * 64 + lx;
+        const double nm1 = col[-64], np1 = col[64], own = col[0], s1 = nm1 + np1, d1 = nm1 - np1;
+        if constexpr (KU == 2) {
+          double s2 = 0.0, d2 = 0.0;
+          if (!odd_row) { const double nm2 = col[-128], np2 = col[128]; s2 = nm2 + np2; d2 = np2 - nm2; }
+          My[c] = fma(2.0, s1, cMy * own) - s2; Ky[c] = fma(-8.0, s1, cKy * own) + s2; Oy[c] = fma(4.0, d1, d2);
+        } else { My[c] = fma(cMy, own, s1); Ky[c] = fma(cKy, own, -s1); Oy[c] = d1; }
+        Dy[c] = cDy * own;
+      }
+      auto xstage = [&](const double FK, const double FM, const double FO, const double FD) {
+        if constexpr (KU == 2) {
+          const double t1 = fma(-8.0, FK, 2.0 * FM), t2 = pe * (FK - FM), pO = pe * FO;
+          double sacc = fma(cKx, FK, fma(cMx, FM, cDx * FD));
+          sacc += wave_up1(fma(4.0, FO, t1)) + wave_dn1(fma(-4.0, FO, t1));
+          sacc += wave_up1(wave_up1(t2 - pO)) + wave_dn1(wave_dn1(t2 + pO));
+          return sacc;
+        } else {
+          const double t1 = FM - FK;
+          return fma(cKx, FK, fma(cMx, FM, cDx * FD)) + wave_up1(t1 + FO) + wave_dn1(t1 - FO);
+        }
+      };
+      // K.xk_* = (l+2G | G) sKx sMy, K.m_lKyMz / m_gKyMz = (l+2G | G) sMx sKy, K.cc_mz = {-(l+G), l-G, G-l, l+G} sC^2
+      const double yx = xstage(K.xk_l2g * My[0], K.m_gKyMz * Ky[0], fma(K.cc_mz[1], Dy[1], K.cc_mz[0] * Oy[1]), fma(K.cc_mz[3], Dy[1], K.cc_mz[2] * Oy[1]));
+      const double yy = xstage(K.xk_g * My[1], K.m_lKyMz * Ky[1], fma(K.cc_mz[2], Dy[0], K.cc_mz[0] * Oy[0]), fma(K.cc_mz[3], Dy[0], K.cc_mz[1] * Oy[0]));
+      if (out) { y[node * 2] = yx; y[node * 2 + 1] = yy; dot_acc = fma(u[0], yx, fma(u[1], yy, dot_acc)); }
+    }
+    if (tile + (int)gridDim.x < ntiles) __syncthreads();
+  }
+  if (a.dot_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_xor(dot_acc, off, 64);
+    if (lx == 0) sdot[r] = dot_acc;
+    __syncthreads();
+    if (tid == 0) { double t = 0; for (int q = 0; q < 16; ++q) t += sdot[q]; a.dot_partials[blockIdx.x] = t; }
+  }
+}
+
 // y_i = diag_i x_i on the Dirichlet rows (ConstraintMatrix elimination), from the constraint list
 __global__ void __launch_bounds__(256)
 k_kron_fix_constrained(int64_t n, const int32_t *__restrict__ dofs, const double *__restrict__ diag_local, const double *__restrict__ x, double *__restrict__ y,
@@ -465,14 +544,29 @@ void check_q2_element_matrices() {
 
 }  // namespace
 
-bool kron_supported(int dim, int k_u) { return dim == 3 && (k_u == 1 || k_u == 2); }
+bool kron_supported(int dim, int k_u) { return (dim == 2 || dim == 3) && (k_u == 1 || k_u == 2); }
 
 int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1, const PcgScalars *pcg) {
   static bool checked = false;
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
   const int ku = m.k_u;
-  for (int d = 0; d < 3; ++d) a.nn[d] = ku * m.box.n[d] + 1;
+  for (int d = 0; d < 3; ++d) a.nn[d] = d < m.dim ? ku * m.box.n[d] + 1 : 1;
+  if (m.dim == 2) {
+    const int H = ku == 2 ? 2 : 1, VX = 64 - 2 * H, VY = 16 - 2 * H;
+    const int64_t ntiles = (int64_t)((a.nn[0] + VX - 1) / VX) * ((a.nn[1] + VY - 1) / VY);
+    a.nblocks = (int)ntiles;
+    const double lam = m.lam, G = m.G, l2g = lam + 2 * G, c[4] = {-(lam + G), lam - G, G - lam, lam + G};
+    const double mdiv = ku == 2 ? 30.0 : 6.0, kmul = ku == 2 ? 1.0 / 3.0 : 1.0, sC = ku == 2 ? 1.0 / 6 : 0.5;
+    const double sMx = m.box.h[0] / mdiv, sMy = m.box.h[1] / mdiv, sKx = kmul / m.box.h[0], sKy = kmul / m.box.h[1];
+    a.k.xk_l2g = l2g * sKx * sMy; a.k.xk_g = G * sKx * sMy; a.k.m_lKyMz = l2g * sMx * sKy; a.k.m_gKyMz = G * sMx * sKy;
+    for (int i = 0; i < 4; ++i) a.k.cc_mz[i] = c[i] * sC * sC;
+    a.nodemask = m.nodemask; a.constrained = constrained ? 1 : 0; a.mask_anywhere = m.mask_anywhere; a.dot_partials = dot_partials; a.pcg = pcg;
+    const unsigned grid = (unsigned)(dot_partials ? std::min<int64_t>(ntiles, kMaxPartials) : ntiles);
+    if (ku == 2) hipExtLaunchKernelGGL(k_kron2<2>, dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
+    else hipExtLaunchKernelGGL(k_kron2<1>, dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
+    return (int)grid;
+  }
   // tile shapes: (64 lanes x 16 rows) and (32 x 32); valid outputs 60 x 12 / 28 x 28 for Q2 (halo 2), 62 x 14 / 30 x 30 for Q1 (halo 1)
   const int vx64 = ku == 2 ? 60 : 62, vx32 = ku == 2 ? 28 : 30, vy64 = ku == 2 ? 12 : 14, vy32 = ku == 2 ? 28 : 30, halo = ku == 2 ? 2 : 1;
   // x-extent = full 64-lane tiles + (when what is left fits) one 32-lane tile column
