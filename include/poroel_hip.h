@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PORO_ABI_VERSION 1
+#define PORO_ABI_VERSION 2   /* 2: poro_solver_opts.omega, PORO_PREC_SSOR / FDM / ILU0, PORO_VEC_STRESS0 */
 
 /* Reference-cell tables: exactly the numbers the reference pulls out of
  * FEValues / FEFaceValues (PoroElasticDisplacementSolver.h:162-173,
@@ -138,7 +138,7 @@ typedef struct poro_solver_opts {
 
 /* PORO_PREC_SSOR = PreconditionSSOR in the matrix's natural row order (level-scheduled sweeps; assembled-CSR operators only):
  * reproduces the reference's Krylov iterates, at many small launches per application - a fidelity mode, not the fast path.
- * PORO_PREC_FDM = fast diagonalisation: on a uniform box (poro_desc.box.enabled, one rank) the pressure Jacobian and the projection
+ * PORO_PREC_FDM = fast diagonalisation: on a uniform box (poro_desc.box.enabled; slab-partitioned runs included) the pressure Jacobian and the projection
  * mass matrix are sums of Kronecker products of 1D matrices and are inverted exactly by 2*dim batched dense transforms (fp64 MFMA);
  * CG keeps the reference's stopping rule and needs 1-2 iterations.  poro_supports_preconditioner() tells whether a context can.
  * PORO_PREC_ILU0 = incomplete LU on the pattern of the assembled CSR matrix (factorised on the host once per matrix, level-scheduled
