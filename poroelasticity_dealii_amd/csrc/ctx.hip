@@ -697,6 +697,30 @@ int poro_ctx_comm_init_rccl(poro_ctx *c, const void *id128) {
     PORO_NCCL(g_rccl.GroupEnd());
     PORO_HIP(hipMemcpyAsync(h, t.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
     if (h[0] != 0.5 * nr * (nr + 1) || h[1] != 2.0 * nr || h[3] != 100.0 + down) throw Error("RCCL self-test failed (all-reduce / send-recv returned wrong data)");
+    // the two exchange patterns of the solver, on one double each: the bidirectional neighbour exchange of exchange_add and the
+    // all-to-all of the partitioned fast diagonalisation
+    {
+      DevBuf<double> sb, rb; sb.alloc(nr + 2); rb.alloc(nr + 2);
+      std::vector<double> hs(nr + 2), hr(nr + 2, -1.0);
+      for (int q = 0; q < nr; ++q) hs[q] = 1000.0 * rk + q;
+      hs[nr] = 7.0 + rk; hs[nr + 1] = 9.0 + rk;
+      PORO_HIP(hipMemcpyAsync(sb.p, hs.data(), (nr + 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      PORO_HIP(hipMemcpyAsync(rb.p, hr.data(), (nr + 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      const bool has_up = rk + 1 < nr, has_dn = rk > 0;
+      PORO_NCCL(g_rccl.GroupStart());
+      if (has_up) { PORO_NCCL(g_rccl.Send(sb.p + nr, 1, ncclFloat64, rk + 1, comm, c->stream)); PORO_NCCL(g_rccl.Recv(rb.p + nr, 1, ncclFloat64, rk + 1, comm, c->stream)); }
+      if (has_dn) { PORO_NCCL(g_rccl.Send(sb.p + nr + 1, 1, ncclFloat64, rk - 1, comm, c->stream)); PORO_NCCL(g_rccl.Recv(rb.p + nr + 1, 1, ncclFloat64, rk - 1, comm, c->stream)); }
+      PORO_NCCL(g_rccl.GroupEnd());
+      PORO_NCCL(g_rccl.GroupStart());
+      for (int q = 0; q < nr; ++q) if (q != rk) { PORO_NCCL(g_rccl.Send(sb.p + q, 1, ncclFloat64, q, comm, c->stream)); PORO_NCCL(g_rccl.Recv(rb.p + q, 1, ncclFloat64, q, comm, c->stream)); }
+      PORO_NCCL(g_rccl.GroupEnd());
+      PORO_HIP(hipMemcpyAsync(hr.data(), rb.p, (nr + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+      bool ok = true;
+      if (has_up && hr[nr] != 9.0 + (rk + 1)) ok = false;          // the upper neighbour's "down" message
+      if (has_dn && hr[nr + 1] != 7.0 + (rk - 1)) ok = false;      // the lower neighbour's "up" message
+      for (int q = 0; q < nr; ++q) if (q != rk && hr[q] != 1000.0 * q + rk) ok = false;
+      if (!ok) throw Error("RCCL self-test failed (neighbour exchange / all-to-all returned wrong data)");
+    }
     return 0;
   });
 }
