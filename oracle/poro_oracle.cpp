@@ -693,7 +693,8 @@ void oracle_derived_parameters(double E, double nu, double alpha, double poro, d
 // trace rows (per FSS iteration): [step, fss_iteration, pressure_iterations, pressure_error_inner, |p|_inf, error_after_disp, disp_cg_its, pres_cg_its_total]
 // solver controls are the reference's unless overridden (abs_u, rel_u, max_it, prec, omega_u).
 int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_tol, double pressure_tol, int max_fss, int max_pres,
-               double abs_u, double rel_u, int max_it, int prec, double *trace, int max_rows, double *seconds_per_phase /*[4]: assemble_u, solve_u, projection, pressure*/) {
+               double abs_u, double rel_u, int max_it, int prec, double *trace, int max_rows, double *seconds_per_phase /*[4]: assemble_u, solve_u, projection, pressure*/,
+               int coupled_fss /* 0 = the reference (get_volumetric_strain() commented out at :399); 1 = that call restored: a real fixed-stress iteration */) {
   Oracle *o = reinterpret_cast<Oracle *>(c);
   const int dim = o->dim; int rows = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -740,6 +741,7 @@ int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_
       t0 = now(); o->assemble_system(); tph[0] += now() - t0;      // :395
       t0 = now(); su = o->disp_solve(abs_u, rel_u, max_it, prec, om_u); tph[1] += now() - t0;   // :396
       normal_strains();                                            // :398   (get_volumetric_strain() is commented out, :399)
+      if (coupled_fss) o->get_volumetric_strain();
       t0 = now(); pressure_error = o->assemble_residual(dt); tph[3] += now() - t0;   // :402-405
       if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = step; r[1] = fss; r[2] = pit - 1; r[3] = inner_err; r[4] = pinf; r[5] = pressure_error; r[6] = su.iterations; r[7] = pcg; }
     }

@@ -43,6 +43,8 @@ struct RunControls {
   double fss_tol = 1e-8, pressure_tol = 1e-8; int max_fss_iterations = 50, max_pressure_iterations = 50;
   double abs_tol_u = 1e-12, rel_tol_u = 0.0; int max_iter = 1000;   // PoroElasticDisplacementSolver.h:298-299
   int preconditioner = PORO_PREC_JACOBI;                            // displacement solve; PORO_PREC_SSOR = the reference's PreconditionSSOR (CSR operator, one rank) for all three systems
+  bool coupled_fss = false;                                         // true = restore the get_volumetric_strain() call the reference commented out (:399): eps_v follows the new
+                                                                    // displacement inside the fixed-stress loop, which then really iterates (SURVEY 8f-4 "corrected physics", first half)
   bool corrected_postprocessing = false;                            // false = the reference's output (shear RHS never assembled, 2D "sigma_yy" shows sigma_xx); true = both fixed
   std::string output_dir;                                           // "" = no files; the reference always writes ./solution/solution-NNNN.vtk (:285-290)
   int preconditioner_p = -1;                                        // pressure / projection solves; -1 = fast diagonalisation where the context supports it, else Jacobi
@@ -284,6 +286,7 @@ template <int dim> class PoroElasticProblem {
       assemble_displacement();                             // :395
       solve_displacement();                                // :396
       normal_strains();                                    // :398  (get_volumetric_strain() stays commented out, :399)
+      if (rc.coupled_fss) get_volumetric_strain();
       pressure_solver.assemble_residual(rc.time_step, volumetric_strain, initial_volumetric_strain); work.residual_p++;   // :402-404
       pressure_error = pressure_solver.residual_l2;        // :405
       if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = time_step_number; r[1] = fss_iteration; r[2] = pressure_iteration - 1; r[3] = inner; r[4] = pinf; r[5] = pressure_error; r[6] = displacement_solver.last.iterations; r[7] = pcg; }

@@ -486,3 +486,27 @@ def test_transient_of_ten_steps_tracks_the_oracle():
             G.close()
     finally:
         O.close(); P.close()
+
+
+@pytest.mark.parametrize("dim,n,deg", [(2, 8, 2), (3, 3, 2)])
+def test_coupled_fixed_stress_iteration(dim, n, deg):
+    """`coupled_fss`: the get_volumetric_strain() call the reference commented out (PoroelasticityFSS.h:399) restored.  The fixed-stress loop
+    (:347-407) then really iterates: several coupling iterations per step with a contracting error, the same counts as the oracle."""
+    P = box_problem(dim, n, deg, mat=host_material())
+    O = oracle_py.Oracle(P)
+    try:
+        t0, _ = O.run(2, REF["p_init"], REF["dt"], max_it=2000, coupled_fss=True)
+        t1, G = pk.run_problem(P, 2, REF["p_init"], REF["dt"], operator_mode=pk.OP_MATRIX_FREE, max_it=5000, coupled_fss=True)
+        try:
+            assert t1.shape == t0.shape and np.array_equal(t1[:, :3], t0[:, :3])
+            step1 = t1[t1[:, 0] == 1]
+            if dim == 2:                                                             # (on the 3^3 mesh the coupling error is below the tolerance at once)
+                assert len(step1) > 1                                                # more than one coupling iteration per step
+            assert np.all(np.diff(step1[:, 5]) < 0) and step1[-1, 5] <= 1e-8      # contracting, converged
+            assert np.allclose(t1[:, 4], t0[:, 4], rtol=1e-9)
+            assert rel2(G.get(pk.VEC_P), O.get(pk.VEC_P)) <= 1e-9
+            assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-7
+        finally:
+            G.close()
+    finally:
+        O.close(); P.close()
