@@ -190,10 +190,10 @@ class Oracle:
         self._cb = (ALLREDUCE_FN(_ar), SENDRECV_FN(_sr))
         self.L.oracle_set_comm(self.ptr, self._cb[0], self._cb[1], None)
 
-    def run(self, n_steps, p_init, dt, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50, abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_SSOR, coupled_fss=False):
+    def run(self, n_steps, p_init, dt, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50, abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_SSOR, coupled_fss=False, incremental_strain=False):
         """PoroElasticProblem<dim>::run() restatement; returns (trace[rows,8], seconds_per_phase[4])."""
         max_rows = 1 + n_steps * max_fss
         trace, tph = np.zeros((max_rows, 8)), np.zeros(4)
         rows = self.L.oracle_run(self.ptr, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec,
-                                 trace.ctypes.data_as(_dp), max_rows, tph.ctypes.data_as(_dp), int(coupled_fss))
+                                 trace.ctypes.data_as(_dp), max_rows, tph.ctypes.data_as(_dp), int(bool(coupled_fss)) | (2 if incremental_strain else 0))
         return trace[:rows], tph

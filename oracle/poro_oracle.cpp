@@ -694,7 +694,8 @@ void oracle_derived_parameters(double E, double nu, double alpha, double poro, d
 // solver controls are the reference's unless overridden (abs_u, rel_u, max_it, prec, omega_u).
 int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_tol, double pressure_tol, int max_fss, int max_pres,
                double abs_u, double rel_u, int max_it, int prec, double *trace, int max_rows, double *seconds_per_phase /*[4]: assemble_u, solve_u, projection, pressure*/,
-               int coupled_fss /* 0 = the reference (get_volumetric_strain() commented out at :399); 1 = that call restored: a real fixed-stress iteration */) {
+               int coupled_fss /* bit 0: 0 = the reference (get_volumetric_strain() commented out at :399), 1 = that call restored: a real fixed-stress iteration;
+                                   bit 1: strain increment taken against the PREVIOUS step (eps_v^n) instead of the initial state (:317, :361-363) */) {
   Oracle *o = reinterpret_cast<Oracle *>(c);
   const int dim = o->dim; int rows = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -720,6 +721,7 @@ int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_
   if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = 0; r[5] = 0; r[6] = su.iterations; r[7] = 0; }
   for (int step = 1; step <= n_steps; ++step) {                    // :327 (AMR branch :333-340 out of scope)
     o->p_old = o->p;                                               // :342
+    if ((coupled_fss & 2) && step > 1) o->eps_v0 = o->eps_v;       // corrected storage term: alpha (eps_v^{n+1} - eps_v^n) / dt
     double pressure_error = pressure_tol * 2; int fss = 0;         // :345-346
     while (fss < max_fss && pressure_error > fss_tol) {            // :347-348
       ++fss; int pit = 0; int pcg = 0; double inner_err = 0;
@@ -741,7 +743,7 @@ int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_
       t0 = now(); o->assemble_system(); tph[0] += now() - t0;      // :395
       t0 = now(); su = o->disp_solve(abs_u, rel_u, max_it, prec, om_u); tph[1] += now() - t0;   // :396
       normal_strains();                                            // :398   (get_volumetric_strain() is commented out, :399)
-      if (coupled_fss) o->get_volumetric_strain();
+      if (coupled_fss & 1) o->get_volumetric_strain();
       t0 = now(); pressure_error = o->assemble_residual(dt); tph[3] += now() - t0;   // :402-405
       if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = step; r[1] = fss; r[2] = pit - 1; r[3] = inner_err; r[4] = pinf; r[5] = pressure_error; r[6] = su.iterations; r[7] = pcg; }
     }

@@ -45,6 +45,7 @@ struct RunControls {
   int preconditioner = PORO_PREC_JACOBI;                            // displacement solve; PORO_PREC_SSOR = the reference's PreconditionSSOR (CSR operator, one rank) for all three systems
   bool coupled_fss = false;                                         // true = restore the get_volumetric_strain() call the reference commented out (:399): eps_v follows the new
                                                                     // displacement inside the fixed-stress loop, which then really iterates (SURVEY 8f-4 "corrected physics", first half)
+  bool incremental_strain = false;                                  // true = storage term against the previous step, alpha (eps_v - eps_v^n) / dt, instead of the initial state eps_v0 (:317, :361-363)
   bool corrected_postprocessing = false;                            // false = the reference's output (shear RHS never assembled, 2D "sigma_yy" shows sigma_xx); true = both fixed
   std::string output_dir;                                           // "" = no files; the reference always writes ./solution/solution-NNNN.vtk (:285-290)
   int preconditioner_p = -1;                                        // pressure / projection solves; -1 = fast diagonalisation where the context supports it, else Jacobi
@@ -264,6 +265,7 @@ template <int dim> class PoroElasticProblem {
     int rows = 0;
     time_step_number++;                                    // :329
     pressure_solver.old_solution = pressure_solver.solution;   // :342
+    if (rc.incremental_strain && time_step_number > 1) initial_volumetric_strain = volumetric_strain;
     double pressure_error = rc.pressure_tol * 2; int fss_iteration = 0;   // :345-346
     while (fss_iteration < rc.max_fss_iterations && pressure_error > rc.fss_tol) {   // :347-348
       fss_iteration++;

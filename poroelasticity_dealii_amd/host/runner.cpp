@@ -1,4 +1,4 @@
-// Driver executable: `poro_run input.data [--mesh domain.msh] [--degree 1|2] [--matrix-free] [--ssor] [--steps N] [--output DIR] [--corrected-output] [--coupled-fss]`.
+// Driver executable: `poro_run input.data [--mesh domain.msh] [--degree 1|2] [--matrix-free] [--ssor] [--steps N] [--output DIR] [--corrected-output] [--coupled-fss] [--incremental-strain]`.
 // Stands in for the reference's missing code/source/Runner.cpp (code/CMakeLists.txt:8): argv[1] is the
 // parameter file (parse_command_line.h:5-27); the mesh is create_mesh()'s colorized box refined
 // `Initial refinement level` times (PoroelasticityFSS.h:418-435) unless --mesh names a Gmsh file
@@ -16,7 +16,7 @@ using namespace poro_host;
 
 int main(int argc, char **argv) {
   if (argc < 2) { std::cerr << "specify the file name" << std::endl; return 1; }   // parse_command_line.h:9-13
-  std::string mesh_file; int degree = 2, op = PORO_OP_CSR, steps = -1, device = 0, prec = PORO_PREC_JACOBI; std::string output_dir; bool corrected = false, coupled = false;
+  std::string mesh_file; int degree = 2, op = PORO_OP_CSR, steps = -1, device = 0, prec = PORO_PREC_JACOBI; std::string output_dir; bool corrected = false, coupled = false, incremental = false;
   for (int i = 2; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--mesh") && i + 1 < argc) mesh_file = argv[++i];
     else if (!std::strcmp(argv[i], "--degree") && i + 1 < argc) degree = std::atoi(argv[++i]);
@@ -25,6 +25,7 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--matrix-free")) op = PORO_OP_MATRIX_FREE;
     else if (!std::strcmp(argv[i], "--output") && i + 1 < argc) output_dir = argv[++i];
     else if (!std::strcmp(argv[i], "--corrected-output")) corrected = true;
+    else if (!std::strcmp(argv[i], "--incremental-strain")) incremental = true;   // storage term against the previous step instead of the initial state
     else if (!std::strcmp(argv[i], "--coupled-fss")) coupled = true;    // restore get_volumetric_strain() inside the fixed-stress loop (:399)
     else if (!std::strcmp(argv[i], "--ssor")) prec = PORO_PREC_SSOR;   // the reference's PreconditionSSOR instead of Jacobi
     else { std::cerr << "unknown option " << argv[i] << std::endl; return 1; }
@@ -46,7 +47,7 @@ int main(int argc, char **argv) {
       for (int d = 0; d < data.dim; ++d) { n[d] = 1 << data.initial_refinement_level; size[d] = data.domain_size.at(d); }
       build_box_problem(P, data.dim, n, size, degree);
     }
-    RunControls rc; rc.preconditioner = prec; rc.output_dir = output_dir; rc.corrected_postprocessing = corrected; rc.coupled_fss = coupled;
+    RunControls rc; rc.preconditioner = prec; rc.output_dir = output_dir; rc.corrected_postprocessing = corrected; rc.coupled_fss = coupled; rc.incremental_strain = incremental;
     rc.p_init = data.p_init; rc.time_step = data.time_step; rc.fss_tol = data.fss_tol; rc.pressure_tol = data.pressure_tol;
     rc.max_fss_iterations = data.max_fss_iterations; rc.max_pressure_iterations = data.max_pressure_iterations;
     int n_steps = 0; for (double t = 0; t < data.t_max; t += data.time_step) ++n_steps;   // while (time < t_max) (:327)

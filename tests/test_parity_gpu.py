@@ -488,15 +488,16 @@ def test_transient_of_ten_steps_tracks_the_oracle():
         O.close(); P.close()
 
 
-@pytest.mark.parametrize("dim,n,deg", [(2, 8, 2), (3, 3, 2)])
-def test_coupled_fixed_stress_iteration(dim, n, deg):
+@pytest.mark.parametrize("dim,n,deg,incremental", [(2, 8, 2, False), (3, 3, 2, False), (2, 8, 2, True)])
+def test_coupled_fixed_stress_iteration(dim, n, deg, incremental):
     """`coupled_fss`: the get_volumetric_strain() call the reference commented out (PoroelasticityFSS.h:399) restored.  The fixed-stress loop
     (:347-407) then really iterates: several coupling iterations per step with a contracting error, the same counts as the oracle."""
     P = box_problem(dim, n, deg, mat=host_material())
     O = oracle_py.Oracle(P)
     try:
-        t0, _ = O.run(2, REF["p_init"], REF["dt"], max_it=2000, coupled_fss=True)
-        t1, G = pk.run_problem(P, 2, REF["p_init"], REF["dt"], operator_mode=pk.OP_MATRIX_FREE, max_it=5000, coupled_fss=True)
+        # `incremental`: additionally the storage term against the previous step's strain instead of the initial one (3 steps, so it matters)
+        t0, _ = O.run(3, REF["p_init"], REF["dt"], max_it=2000, coupled_fss=True, incremental_strain=incremental)
+        t1, G = pk.run_problem(P, 3, REF["p_init"], REF["dt"], operator_mode=pk.OP_MATRIX_FREE, max_it=5000, coupled_fss=True, incremental_strain=incremental)
         try:
             assert t1.shape == t0.shape and np.array_equal(t1[:, :3], t0[:, :3])
             step1 = t1[t1[:, 0] == 1]
