@@ -125,6 +125,7 @@ struct poro_ctx {
   poro::DevBuf<double> dinv_u, dinv_J, dinv_M;   // reciprocals of the Jacobi diagonals
   poro::DevBuf<uint8_t> diag_u_cls; poro::DevBuf<double> diag_u_tab;   // dictionary form of diag_u (uniform boxes): class per node + table[class][dim]
   poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
+  bool box_asm_checked = false;
   int box_asm = 0 /* 0 off, 1 unchecked, 2 checked against the per-cell kernels */; poro::BoxCoupling box_cpl{};
   poro::DevBuf<double> ilu_u, ilu_J, ilu_M; bool ilu_u_valid = false, ilu_J_valid = false, ilu_M_valid = false;   // ILU(0) factors on the CSR patterns
   poro::DevBuf<double> wz_p;   // z = P^-1 g of an explicit preconditioner (pressure-sized systems)
@@ -209,6 +210,7 @@ void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double
 bool kron_supported(int dim, int k_u);
 BoxCoupling box_coupling(int dim, int k_u, const BoxDev &box);
 void box_rhs_u(hipStream_t s, int dim, const BoxCoupling &B, double alpha, const double *p, const double *lift, const double *neu, const uint8_t *mask, double *rhs);
+void box_asm_u_matrix(hipStream_t s, int dim, int k_u, const BoxDev &box, const double *Ke, const CsrDev &A, const uint8_t *mask, double *val);
 void box_proj_rhs(hipStream_t s, int dim, const BoxCoupling &B, const double *u, int n_comp, const int32_t *tensor_components, double *const *rhs);
 void q1_eig(int n_cells, double h, std::vector<double> &S, std::vector<double> &lam);   // host: generalised eigenpairs of the 1D Q1 stiffness / mass matrices
 void fdm_window(hipStream_t s, double *dst, const double *src, bool to_block, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid, int64_t grid_stride, int64_t grid_col0, int64_t grid_plane0);

@@ -763,7 +763,27 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
     if (rebuild_matrix || !c->matrix_built) {
       Timed tm(c, "assemble_u_matrix");
       c->lift_u.zero(s); c->neumann_u.zero(s);
-      if (c->operator_mode == PORO_OP_CSR) {
+      if (c->operator_mode == PORO_OP_CSR && c->box_asm) {
+        // uniform box: one element matrix, every CSR entry written once by its owner (kernels_box.hip); the lifting -(A_full g) comes
+        // from the unconstrained structured operator
+        if (!c->Ke.p) c->Ke.alloc((size_t)c->dpc_u * c->dpc_u);
+        asm_u_element_matrix(s, a, 0, c->Ke.p);
+        box_asm_u_matrix(s, c->dim, c->k_u, c->box, c->Ke.p, c->Au, c->dir_mask.p, c->Au_val.p);
+        if (!c->box_asm_checked && c->Au.nnz <= 60000000 && !std::getenv("PORO_DIAG_SKIP_SELFCHECK")) {   // once, against the coloured per-cell assembly
+          DevBuf<double> ref, lift_ref; ref.alloc(c->Au.nnz); ref.zero(s); lift_ref.alloc(c->n_u); lift_ref.zero(s);
+          for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
+            asm_u_matrix(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], c->Au.rp.p, c->Au.col.p, ref.p, lift_ref.p);
+          la_axpy(s, ref.p, -1.0, c->Au_val.p, c->Au.nnz);
+          la_norm_partials(s, ref.p, c->Au.nnz, c->partials.p, c->partials.p + kMaxPartials); la_norm_partials(s, c->Au_val.p, c->Au.nnz, c->partials.p + 2 * kMaxPartials, c->partials.p + 3 * kMaxPartials);
+          la_reduce_finish(s, c->partials.p, 4, c->red.p, 2 | 8);
+          double h[4]; PORO_HIP(hipMemcpyAsync(h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+          if (!(h[1] <= 1e-12 * h[3])) throw Error("structured CSR assembly disagrees with the per-cell assembly: max diff " + std::to_string(h[1]) + " vs max " + std::to_string(h[3]));
+        }
+        c->box_asm_checked = true;
+        mf_operator(c, c->dir_val.p, c->wh_u.p, false);
+        la_fill(s, c->lift_u.p, 0.0, c->n_u); la_axpy(s, c->lift_u.p, -1.0, c->wh_u.p, c->n_u);
+        la_csr_diag(s, c->Au, c->Au_val.p, c->diag_u_local.p);
+      } else if (c->operator_mode == PORO_OP_CSR) {
         c->Au_val.zero(s);
         for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
           asm_u_matrix(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], c->Au.rp.p, c->Au.col.p, c->Au_val.p, c->lift_u.p);

@@ -137,7 +137,62 @@ k_box_proj_rhs(BoxCoupling B, const double *__restrict__ u, BoxProjOut out) {
   }
 }
 
+// ---- K-asm-u on a uniform box: every cell matrix is the same Ke, so each CSR entry is written ONCE by its owner (no colouring, no
+// read-modify-write): A(r, c) = sum over the <= 2^dim cells that contain both nodes of Ke[local(r)][local(c)], Dirichlet rows / columns
+// eliminated as in distribute_local_to_global (sum of |K_ii| on the constrained diagonal).  L lanes per CSR row as in k_spmv.
+template <int DIM, int K, int L> __global__ void __launch_bounds__(256)
+k_box_asm_u(int n0, int n1, int n2, const double *__restrict__ Ke, int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+            const uint8_t *__restrict__ mask, double *__restrict__ val) {
+  constexpr int N1 = K + 1, NS = DIM == 2 ? N1 * N1 : N1 * N1 * N1, DPC = NS * DIM;
+  const int lane = threadIdx.x % L;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / L;
+  if (row >= n_rows) return;
+  const int nc[3] = {n0, n1, n2};
+  const int nx = K * n0 + 1, ny = K * n1 + 1;
+  const int node_r = (int)(row / DIM), cr = (int)(row - (int64_t)node_r * DIM);
+  const int ir[3] = {node_r % nx, (node_r / nx) % ny, DIM == 3 ? node_r / (nx * ny) : 0};
+  const bool mrow = mask[row] != 0;
+  for (int64_t e = rp[row] + lane; e < rp[row + 1]; e += L) {
+    const int32_t c = col[e];
+    const int node_c = c / DIM, cc = c - node_c * DIM;
+    const int ic[3] = {node_c % nx, (node_c / nx) % ny, DIM == 3 ? node_c / (nx * ny) : 0};
+    int c0[3], cnt[3];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {                            // cells of direction d that contain both indices: K c <= i, j <= K c + K
+      const int hi = ir[d] > ic[d] ? ir[d] : ic[d], lo = ir[d] < ic[d] ? ir[d] : ic[d];
+      int cmin = (hi - K + K - 1) / K; if (hi - K < 0) cmin = 0;
+      int cmax = lo / K; if (cmax > nc[d] - 1) cmax = nc[d] - 1;
+      c0[d] = cmin; cnt[d] = cmax - cmin + 1;
+    }
+    double v = 0.0;
+    const bool diag = c == (int32_t)row;
+    if (!(mrow && !diag) && !(mask[c] && !mrow)) {
+      for (int kz = 0; kz < (DIM == 3 ? cnt[2] : 1); ++kz)
+        for (int ky = 0; ky < cnt[1]; ++ky)
+          for (int kx = 0; kx < cnt[0]; ++kx) {
+            const int cx = c0[0] + kx, cy = c0[1] + ky, cz = DIM == 3 ? c0[2] + kz : 0;
+            const int li = (DIM == 3 ? (ir[2] - K * cz) * N1 * N1 : 0) + (ir[1] - K * cy) * N1 + (ir[0] - K * cx);
+            const int lj = (DIM == 3 ? (ic[2] - K * cz) * N1 * N1 : 0) + (ic[1] - K * cy) * N1 + (ic[0] - K * cx);
+            const double k = Ke[(size_t)(li * DIM + cr) * DPC + lj * DIM + cc];
+            v += mrow ? fabs(k) : k;
+          }
+    }
+    val[e] = v;
+  }
+}
+
 }  // namespace
+
+template <int DIM, int K> static void launch_box_asm(hipStream_t s, const BoxDev &box, const double *Ke, const CsrDev &A, const uint8_t *mask, double *val) {
+  const int64_t grid = (A.n * 64 + 255) / 256;
+  hipLaunchKernelGGL((k_box_asm_u<DIM, K, 64>), (unsigned)grid, 256, 0, s, box.n[0], box.n[1], DIM == 3 ? box.n[2] : 1, Ke, A.n, A.rp.p, A.col.p, mask, val);
+}
+void box_asm_u_matrix(hipStream_t s, int dim, int k_u, const BoxDev &box, const double *Ke, const CsrDev &A, const uint8_t *mask, double *val) {
+  if (dim == 2 && k_u == 1) launch_box_asm<2, 1>(s, box, Ke, A, mask, val);
+  else if (dim == 2) launch_box_asm<2, 2>(s, box, Ke, A, mask, val);
+  else if (k_u == 1) launch_box_asm<3, 1>(s, box, Ke, A, mask, val);
+  else launch_box_asm<3, 2>(s, box, Ke, A, mask, val);
+}
 
 // 1D local blocks on the unit interval: N[s][t] = int phi_s psi_t, D[s][t] = int phi_s' psi_t (Lagrange Q_k on equidistant nodes, Q1)
 BoxCoupling box_coupling(int dim, int k_u, const BoxDev &box) {
