@@ -140,6 +140,8 @@ k_box_proj_rhs(BoxCoupling B, const double *__restrict__ u, BoxProjOut out) {
 // ---- K-asm-u on a uniform box: every cell matrix is the same Ke, so each CSR entry is written ONCE by its owner (no colouring, no
 // read-modify-write): A(r, c) = sum over the <= 2^dim cells that contain both nodes of Ke[local(r)][local(c)], Dirichlet rows / columns
 // eliminated as in distribute_local_to_global (sum of |K_ii| on the constrained diagonal).  L lanes per CSR row as in k_spmv.
+// x / d for 0 <= x < 2^31 through the reciprocal (one correction step): the kernel decomposes a node index per CSR entry
+__device__ __forceinline__ int div_by(int x, int d, double inv) { int q = (int)((double)x * inv); const int r = x - q * d; if (r < 0) --q; else if (r >= d) ++q; return q; }
 template <int DIM, int K, int L> __global__ void __launch_bounds__(256)
 k_box_asm_u(int n0, int n1, int n2, const double *__restrict__ Ke, int64_t n_rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
             const uint8_t *__restrict__ mask, double *__restrict__ val) {
@@ -149,13 +151,16 @@ k_box_asm_u(int n0, int n1, int n2, const double *__restrict__ Ke, int64_t n_row
   if (row >= n_rows) return;
   const int nc[3] = {n0, n1, n2};
   const int nx = K * n0 + 1, ny = K * n1 + 1;
+  const double inx = 1.0 / nx, iny = 1.0 / ny;
   const int node_r = (int)(row / DIM), cr = (int)(row - (int64_t)node_r * DIM);
-  const int ir[3] = {node_r % nx, (node_r / nx) % ny, DIM == 3 ? node_r / (nx * ny) : 0};
+  const int qr = div_by(node_r, nx, inx), zr = DIM == 3 ? div_by(qr, ny, iny) : 0;
+  const int ir[3] = {node_r - qr * nx, qr - zr * ny, zr};
   const bool mrow = mask[row] != 0;
   for (int64_t e = rp[row] + lane; e < rp[row + 1]; e += L) {
     const int32_t c = col[e];
     const int node_c = c / DIM, cc = c - node_c * DIM;
-    const int ic[3] = {node_c % nx, (node_c / nx) % ny, DIM == 3 ? node_c / (nx * ny) : 0};
+    const int qc = div_by(node_c, nx, inx), zc = DIM == 3 ? div_by(qc, ny, iny) : 0;
+    const int ic[3] = {node_c - qc * nx, qc - zc * ny, zc};
     int c0[3], cnt[3];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) {                            // cells of direction d that contain both indices: K c <= i, j <= K c + K
