@@ -26,3 +26,21 @@ for deg in (1, 2):
 with open(os.path.join(HERE, "config1_trace.json"), "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))
+
+# Regression goldens for the box configurations (miniatures of BASELINE configs 2-5): 2 time steps each, reference loop and the
+# coupled variant.  Same provenance: this repository's oracle, not the reference.
+from common import REF, box_problem, host_material  # noqa: E402
+
+boxes = {}
+for name, (dim, n, deg) in {"2d_q2_16": (2, 16, 2), "3d_q1_4": (3, 4, 1), "3d_q2_4": (3, 4, 2)}.items():
+    P = box_problem(dim, n, deg, mat=host_material())
+    for variant, kw in (("reference", {}), ("coupled", {"coupled_fss": True, "incremental_strain": True})):
+        O = oracle_py.Oracle(P)
+        tr, _ = O.run(2, REF["p_init"], REF["dt"], max_it=2000, **kw)
+        boxes[f"{name}_{variant}"] = {"dim": dim, "n": n, "degree": deg, "variant": variant, "rows": tr[:, :6].tolist(), "u_l2": float(np.linalg.norm(O.get(pk.VEC_U))),
+                                      "p_l2": float(np.linalg.norm(O.get(pk.VEC_P))), "p_linf": float(np.abs(O.get(pk.VEC_P)).max()),
+                                      "epsv_l2": float(np.linalg.norm(O.get(pk.VEC_EPSV))), "noconvergence": int(O.noconvergence_count())}
+        O.close()
+    P.close()
+with open(os.path.join(HERE, "box_traces.json"), "w") as f:
+    json.dump(boxes, f, indent=1)

@@ -195,3 +195,23 @@ def test_k7_config1_golden_trace():
         assert abs(np.linalg.norm(O.get(pk.VEC_P)) - g["p_l2"]) <= 1e-10 * g["p_l2"]
         assert abs(np.linalg.norm(O.get(pk.VEC_EPSV)) - g["epsv_l2"]) <= 1e-6 * g["epsv_l2"]
         O.close(); P.close()
+
+
+def test_box_regression_goldens():
+    """Committed oracle traces of three small box configurations (tests/golden/box_traces.json, made by make_golden.py from this oracle): the
+    reference loop and the coupled / incremental variant.  Guards the oracle itself against silent changes."""
+    from common import REF, box_problem, host_material
+    with open(os.path.join(GOLDEN, "box_traces.json")) as f:
+        gold = json.load(f)
+    for name, g in gold.items():
+        P = box_problem(g["dim"], g["n"], g["degree"], mat=host_material())
+        O = oracle_py.Oracle(P)
+        kw = {"coupled_fss": True, "incremental_strain": True} if g["variant"] == "coupled" else {}
+        tr, _ = O.run(2, REF["p_init"], REF["dt"], max_it=2000, **kw)
+        rows = np.array(g["rows"])
+        assert tr.shape[0] == rows.shape[0] and np.array_equal(tr[:, :3], rows[:, :3]), name
+        assert np.allclose(tr[:, 4], rows[:, 4], rtol=1e-10), name
+        assert abs(np.linalg.norm(O.get(pk.VEC_U)) - g["u_l2"]) <= 1e-8 * g["u_l2"], name
+        assert abs(np.linalg.norm(O.get(pk.VEC_P)) - g["p_l2"]) <= 1e-10 * g["p_l2"], name
+        assert O.noconvergence_count() == g["noconvergence"]
+        O.close(); P.close()

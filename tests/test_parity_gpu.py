@@ -511,3 +511,22 @@ def test_coupled_fixed_stress_iteration(dim, n, deg, incremental):
             G.close()
     finally:
         O.close(); P.close()
+
+
+def test_box_regression_goldens_on_device():
+    """The HIP path against the committed traces of tests/golden/box_traces.json (oracle-generated): iteration counts, |p|_inf per step, norms."""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "box_traces.json")) as f:
+        gold = json.load(f)
+    for name, g in gold.items():
+        P = box_problem(g["dim"], g["n"], g["degree"], mat=host_material())
+        kw = {"coupled_fss": True, "incremental_strain": True} if g["variant"] == "coupled" else {}
+        t1, G = pk.run_problem(P, 2, REF["p_init"], REF["dt"], operator_mode=pk.OP_MATRIX_FREE, max_it=5000, **kw)
+        try:
+            rows = np.array(g["rows"])
+            assert t1.shape[0] == rows.shape[0] and np.array_equal(t1[:, :3], rows[:, :3]), name
+            assert np.allclose(t1[:, 4], rows[:, 4], rtol=1e-9), name
+            assert abs(np.linalg.norm(G.get(pk.VEC_P)) - g["p_l2"]) <= 1e-9 * g["p_l2"], name
+            assert abs(np.linalg.norm(G.get(pk.VEC_U)) - g["u_l2"]) <= 1e-7 * g["u_l2"], name
+        finally:
+            G.close(); P.close()
