@@ -205,6 +205,7 @@ void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool c
 void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
 // y = (a M + kappa K) x for the Q1 pressure space of a uniform box (constant-coefficient 3^dim-point stencil)
 void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double kappa, const double *x, double *y);
+void p_residual_stencil(hipStream_t s, int dim, const BoxDev &box, double kappa, const double *t, const double *p, const double *src, double *R);
 
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);

@@ -894,7 +894,8 @@ int poro_pres_assemble_residual(poro_ctx *c, double dt, double *l2) {
     {
       Timed tm(c, "pressure_residual");
       la_pressure_tmp(s, c->tmp_p.p, vec(c, PORO_VEC_EPSV), vec(c, PORO_VEC_EPSV0), vec(c, PORO_VEC_P), vec(c, PORO_VEC_P_OLD), c->mat.biot_alpha / dt, 1. / c->mat.biot_M / dt, c->n_p);
-      la_csr_residual(s, c->Ap, c->Mp.p, c->Kp.p, c->mat.k_over_mu, c->tmp_p.p, vec(c, PORO_VEC_P), c->src_local.p, R);
+      if (c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled) p_residual_stencil(s, c->dim, c->box, c->mat.k_over_mu, c->tmp_p.p, vec(c, PORO_VEC_P), c->src_local.p, R);
+      else la_csr_residual(s, c->Ap, c->Mp.p, c->Kp.p, c->mat.k_over_mu, c->tmp_p.p, vec(c, PORO_VEC_P), c->src_local.p, R);
     }
     exchange_add(c, R, c->n_p, c->comm.part.plane_p);
     la_dot_partials(s, R, R, owned(c, c->n_p, c->comm.part.plane_p), c->partials.p);

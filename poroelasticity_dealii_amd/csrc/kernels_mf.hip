@@ -198,6 +198,22 @@ k_p_stencil(int n0, int n1, int n2, double h0, double h1, double h2, double a, d
   y[node] = p_stencil_row<DIM>(n0, n1, n2, h0, h1, h2, a, kappa, node, x);
 }
 
+// K-res-p on a uniform box: R = -((M t + kappa (K p)) + q), same association as k_residual / the reference (PoroElasticPressureSolver.h:113-155)
+template <int DIM> __global__ void __launch_bounds__(256)
+k_p_residual_stencil(int n0, int n1, int n2, double h0, double h1, double h2, double kappa, const double *__restrict__ t, const double *__restrict__ p,
+                     const double *__restrict__ src, double *__restrict__ R) {
+  const int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= (int64_t)n0 * n1 * n2) return;
+  const double s1 = p_stencil_row<DIM>(n0, n1, n2, h0, h1, h2, 1.0, 0.0, node, t), s2 = p_stencil_row<DIM>(n0, n1, n2, h0, h1, h2, 0.0, 1.0, node, p);
+  R[node] = -((s1 + s2 * kappa) + src[node]);
+}
+void p_residual_stencil(hipStream_t s, int dim, const BoxDev &box, double kappa, const double *t, const double *p, const double *src, double *R) {
+  const int n0 = box.n[0] + 1, n1 = box.n[1] + 1, n2 = dim == 3 ? box.n[2] + 1 : 1;
+  const unsigned grid = (unsigned)(((int64_t)n0 * n1 * n2 + 255) / 256);
+  if (dim == 2) hipLaunchKernelGGL(k_p_residual_stencil<2>, grid, 256, 0, s, n0, n1, n2, box.h[0], box.h[1], 1.0, kappa, t, p, src, R);
+  else hipLaunchKernelGGL(k_p_residual_stencil<3>, grid, 256, 0, s, n0, n1, n2, box.h[0], box.h[1], box.h[2], kappa, t, p, src, R);
+}
+
 void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double kappa, const double *x, double *y) {
   const int n0 = box.n[0] + 1, n1 = box.n[1] + 1, n2 = dim == 3 ? box.n[2] + 1 : 1;
   const int64_t nn = (int64_t)n0 * n1 * n2;
