@@ -10,8 +10,10 @@ produced by an operator application y = A x or by an assembly pass; `value` = Do
 Only useful work is counted: (iterations + 1) operator applications per CG solve (launches the batched PCG loop
 enqueues behind the finishing iteration are no-ops), the Jacobian only when dt changed.
 
-Workload: 3D Q2/Q1 uniform box, 72^3 cells per GPU (N_u = 9 145 875 at 1 GPU: BASELINE config "3D Q2/Q1 ~10M DoF");
-weak scaling: rank r owns a z-slab of 72 cell layers of a 72 x 72 x 72N box (edge 10 x 10 x 10N, same h).
+Workload: 3D Q2/Q1 uniform box of 72^3 cells (N_u = 9 145 875: BASELINE config "3D Q2/Q1 ~10M DoF").  N > 1 cuts THAT mesh into N z-slabs
+(strong scaling: 9 cell layers per GPU at N = 8); the weak-scaled variant (72 layers per GPU, 72 x 72 x 72N box, same h) is measured
+as well and reported under "weak_scaling_line".  Every timed step must do a real displacement solve: the CG stops on the reduction of the
+step's own initial residual (PORO_STOP_REDUCTION), the per-step iteration counts are printed and a step with 0 iterations fails the run.
 Input is synthetic in the sense of SURVEY 8d: the bundled input.data material / BC values on a generated mesh.
 """
 import argparse
@@ -52,13 +54,13 @@ def bytes_per_apply(dim, degree, n_u, n_cells, operator):
     raise ValueError
 
 
-def cpu_baseline(dim, degree, n, rel_tol):
+def cpu_baseline(dim, degree, n, rel_tol, reduction):
     """the oracle (CPU restatement of the reference algorithm, 1 thread) on a bounded sample of the same workload"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     P = pk.Problem.box(dim, [n] * dim, [10.0] * dim, degree, material(), BC_3D[:2 * dim])
     O = oracle_py.Oracle(P)                      # naive i x q x j assembly (quirk Q6) + SSOR-CG = the reference's algorithm
-    kw = dict(abs_u=1e-12, rel_u=rel_tol, max_it=100000)
+    kw = dict(abs_u=1e-12, rel_u=rel_tol, max_it=100000, reduction=reduction)
     ta = time.perf_counter(); O.run(0, INPUT["p_init"], INPUT["dt"], **kw); tb = time.perf_counter()      # initialisation only
     w_init = O.work_counts(reset=True)
     tc = time.perf_counter(); O.run(1, INPUT["p_init"], INPUT["dt"], **kw); td = time.perf_counter()      # initialisation + 1 time step
@@ -99,6 +101,95 @@ def _cpu_name():
     return "unknown"
 
 
+def kernel_source_stamp():
+    """sha256 of the operator-kernel source: PMC traffic figures under profiles/ are only quoted for the build they were measured on"""
+    import hashlib
+    with open(os.path.join(ROOT, "poroelasticity_dealii_amd", "csrc", "kernels_kron.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def committed_traffic(dim, deg, n):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py).  The file carries the stamp of the kernel source it was
+    measured on; a different source (or no file) gives null rather than a stale number."""
+    try:
+        key = {(2, 72): "poro::k_kron3_q2", (1, 99): "poro::k_kron3_q1"}[(deg, n)] if dim == 3 else None
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            rec = json.load(f)
+        if rec.get("kernel_source_sha16") != kernel_source_stamp():
+            return None
+        return rec[key]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist, rccl_ids, prec=None, label="jacobi"):
+    """`warmup` untimed + `steps` timed time steps of one configuration; returns the measurements of this rank (elapsed = max over ranks)"""
+    dim, deg = args.dim, args.degree
+    n, size = [args.n] * dim, [10.0] * dim
+    if world > 1 and scaling == "weak":
+        n[dim - 1] = args.n * world; size[dim - 1] = 10.0 * world
+    P = pk.Problem.box(dim, n, size, deg, material(), BC_3D[:2 * dim], (), rank, world)
+    R = pk.Runner(P, device=local_rank, operator_mode=pk.OP_MATRIX_FREE, p_init=INPUT["p_init"], dt=INPUT["dt"], abs_u=1e-12, rel_u=args.rel_tol, max_it=args.max_iter,
+                  prec=pk.PREC_JACOBI if prec is None else prec, reduction=args.stop == "reduction")
+    G = R.ctx
+    if world > 1 and args.share_gpu:
+        import numpy as np
+
+        def _allreduce(buf):
+            t = torch.from_numpy(buf.copy()); dist.all_reduce(t); buf[:] = t.numpy()
+
+        def _sendrecv(send, recv, peer):
+            ts, tr = torch.from_numpy(np.array(send, copy=True)), torch.empty(len(recv), dtype=torch.float64)
+            for r in [dist.isend(ts, peer), dist.irecv(tr, peer)]:
+                r.wait()
+            recv[:] = tr.numpy()
+        G.comm_callbacks(_allreduce, _sendrecv)
+    elif world > 1:
+        G.comm_rccl(rccl_ids[label + scaling])
+
+    part = P.desc.part                        # shared interface planes are counted once, by their upper owner
+    own_u = P.desc.n_dofs_u - (part.plane_u if part.has_upper else 0)
+    own_p = P.desc.n_dofs_p - (part.plane_p if part.has_upper else 0)
+    n_cells = P.desc.n_cells
+    if world > 1:
+        t = torch.tensor([own_u, own_p, n_cells], dtype=torch.int64); dist.all_reduce(t)
+        n_u_glob, n_p_glob = int(t[0]), int(t[1])
+    else:
+        n_u_glob, n_p_glob = own_u, own_p
+
+    def sync():
+        if torch is not None:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    R.initialize()                            # PoroelasticityFSS.h:308-317 (initial equilibrium; not part of a step)
+    for _ in range(warmup):
+        R.step()
+    before = R.work()
+    G.timers_reset()                          # HIP events around every kernel family on the launch stream
+    sync()
+    t0 = time.perf_counter()
+    traces, step_seconds = [], []
+    for _ in range(steps):
+        ts = time.perf_counter(); traces.append(R.step()[0]); step_seconds.append(time.perf_counter() - ts)   # step() returns after a stream sync
+    sync()
+    elapsed = time.perf_counter() - t0
+    after = R.work()
+    G.timers_enable(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt[0])
+    work = {k: after[k] - before[k] for k in after}
+    families = ("apply_u_matrix_free", "apply_u_dirichlet_rows", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr", "apply_p_stencil",
+                "precondition_p_fdm", "precondition_u_fdm", "halo_exchange", "allreduce", "alltoall")
+    out = {"n": n, "n_u_glob": n_u_glob, "n_p_glob": n_p_glob, "n_u_local": P.desc.n_dofs_u, "n_cells_local": n_cells, "elapsed": elapsed, "work": work,
+           "updates": dof_updates(work, n_u_glob, n_p_glob, dim), "traces": traces, "step_seconds": step_seconds,
+           "kernel_time": {k: G.timer(k) for k in families}}
+    R.close(); P.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,12 +197,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--degree", type=int, default=2)
-    ap.add_argument("--n", "--cells", dest="n", type=int, default=72, help="cells per direction per GPU (use --cells under torch.distributed.run, whose own parser treats --n as an abbreviation)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--rel-tol", type=float, default=1e-10, help="displacement CG: recursive residual <= max(1e-12, rel_tol*||b||) (SURVEY §7 hard parts)")
+    ap.add_argument("--n", "--cells", dest="n", type=int, default=72, help="cells per direction (use --cells under torch.distributed.run, whose own parser treats --n as an abbreviation)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong = the fixed BASELINE mesh (72^3: 9 cell layers per GPU at N = 8, SURVEY 8e) cut into N z-slabs; weak = 72 layers per GPU (reported as an extra key by default)")
+    ap.add_argument("--no-weak-line", action="store_true", help="N > 1: skip the extra weak-scaled measurement")
+    ap.add_argument("--stop", choices=["reduction", "rhs"], default="reduction",
+                    help="displacement CG stops at rel_tol x (reduction: the residual of the step's warm start | rhs: ||b||); with `rhs` a slow transient lets later steps accept the warm start")
+    ap.add_argument("--rel-tol", type=float, default=1e-8, help="displacement CG: recursive residual <= max(1e-12, rel_tol * reference norm of --stop)")
     ap.add_argument("--max-iter", type=int, default=50000)
     ap.add_argument("--cpu-n", type=int, default=9, help="cells per direction of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra time-to-solution measurement with the block fast-diagonalisation preconditioner")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: all ranks use device 0 and exchange through gloo (host-staged callbacks) instead of RCCL")
     ap.add_argument("--trace-out", default=None, help="write the per-step record (SURVEY 8d config 5: FSS / pressure / Krylov iteration counts, wall-clock) to this JSON file")
     args = ap.parse_args()
@@ -135,89 +231,54 @@ def main():
         torch = None
 
     dim, deg = args.dim, args.degree
-    n, size = [args.n] * dim, [10.0] * dim
-    if world > 1 and args.scaling == "weak":
-        n[dim - 1] = args.n * world; size[dim - 1] = 10.0 * world
-    P = pk.Problem.box(dim, n, size, deg, material(), BC_3D[:2 * dim], (), rank, world)
-    R = pk.Runner(P, device=local_rank, operator_mode=pk.OP_MATRIX_FREE, p_init=INPUT["p_init"], dt=INPUT["dt"], abs_u=1e-12, rel_u=args.rel_tol, max_it=args.max_iter)
-    G = R.ctx
-    if world > 1 and args.share_gpu:
-        import numpy as np
-
-        def _allreduce(buf):
-            t = torch.from_numpy(buf.copy()); dist.all_reduce(t); buf[:] = t.numpy()
-
-        def _sendrecv(send, recv, peer):
-            ts, tr = torch.from_numpy(np.array(send, copy=True)), torch.empty(len(recv), dtype=torch.float64)
-            for r in [dist.isend(ts, peer), dist.irecv(tr, peer)]:
-                r.wait()
-            recv[:] = tr.numpy()
-        G.comm_callbacks(_allreduce, _sendrecv)
-    elif world > 1:
-        ids = [pk.rccl_unique_id() if rank == 0 else None]
+    fdm_variant = not args.no_variants
+    weak_line = world > 1 and args.scaling == "strong" and not args.no_weak_line
+    rccl_ids = {}
+    if world > 1 and not args.share_gpu:      # one communicator per context that will be created, ids from rank 0
+        labels = ["jacobi" + args.scaling] + (["fdm" + args.scaling] if fdm_variant else []) + (["jacobiweak"] if weak_line else [])
+        ids = [{lb: pk.rccl_unique_id() for lb in labels} if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        G.comm_rccl(ids[0])
+        rccl_ids = ids[0]
 
-    part = P.desc.part                        # shared interface planes are counted once, by their upper owner
-    own_u = P.desc.n_dofs_u - (part.plane_u if part.has_upper else 0)
-    own_p = P.desc.n_dofs_p - (part.plane_p if part.has_upper else 0)
-    n_cells = P.desc.n_cells
-    if world > 1:
-        t = torch.tensor([own_u, own_p, n_cells], dtype=torch.int64); dist.all_reduce(t)
-        n_u_glob, n_p_glob, n_cells_glob = int(t[0]), int(t[1]), int(t[2])
-    else:
-        n_u_glob, n_p_glob, n_cells_glob = own_u, own_p, n_cells
-
-    def sync():
-        if torch is not None:
-            torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    R.initialize()                            # PoroelasticityFSS.h:308-317 (initial equilibrium; not part of a step)
-    for _ in range(args.warmup):
-        R.step()
-    before = R.work()
-    G.timers_reset()                          # HIP events around every kernel family on the launch stream
-    sync()
-    t0 = time.perf_counter()
-    traces, step_seconds = [], []
-    for _ in range(args.steps):
-        ts = time.perf_counter(); traces.append(R.step()[0]); step_seconds.append(time.perf_counter() - ts)   # step() returns after a stream sync
-    sync()
-    elapsed = time.perf_counter() - t0
-    after = R.work()
-    G.timers_enable(False)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt[0])
-    work = {k: after[k] - before[k] for k in after}
-    updates = dof_updates(work, n_u_glob, n_p_glob, dim)
+    M = run_case(args, args.scaling, args.steps, args.warmup, rank, world, local_rank, torch, dist, rccl_ids)
+    work, elapsed, updates, traces, step_seconds = M["work"], M["elapsed"], M["updates"], M["traces"], M["step_seconds"]
+    n, n_u_glob, n_p_glob = M["n"], M["n_u_glob"], M["n_p_glob"]
+    kernel_time = M["kernel_time"]
 
     # roofline of the dominant kernel: the matrix-free A_u application (per launch, per GPU)
     # launches enqueued behind the finishing iteration of a solve return at once (no-ops, ~2 us): their time stays in the numerator, but the
     # average is taken over the useful applications only (conservative by ~0.2 %)
-    t_apply, n_launched = G.timer("apply_u_matrix_free")
+    t_apply, n_launched = kernel_time["apply_u_matrix_free"]
     n_apply = int(work["apply_u"]) or n_launched
     avg_apply = t_apply / max(n_apply, 1)
-    alg_bytes = bytes_per_apply(dim, deg, P.desc.n_dofs_u, P.desc.n_cells, "matrix_free")
+    alg_bytes = bytes_per_apply(dim, deg, M["n_u_local"], M["n_cells_local"], "matrix_free")
     achieved = alg_bytes / avg_apply / 1e9 if n_apply else 0.0
-    t_fix, n_fix = G.timer("apply_u_dirichlet_rows")
-    kernel_time = {k: G.timer(k) for k in ("apply_u_matrix_free", "apply_u_dirichlet_rows", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr", "apply_p_stencil",
-                                           "precondition_p_fdm", "halo_exchange", "allreduce", "alltoall")}
-
-    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    # tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py); null when no profile is committed
+    t_fix, n_fix = kernel_time["apply_u_dirichlet_rows"]
     kernel_label = ("k_kron3_q%d" % deg if dim == 3 else "k_kron2<%d>" % deg) + " (matrix-free y = A_u x, sum-factorised)"
-    traffic = None
-    try:
-        # committed PMC passes of tools/bench_ops.py on the two BASELINE meshes of the structured kernels (config 4: 72^3 Q2, config 3: 99^3 Q1)
-        key = {(2, 72): "poro::k_kron3_q2", (1, 99): "poro::k_kron3_q1"}[(deg, args.n)] if dim == 3 else None
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v7.json")) as f:
-            traffic = json.load(f)[key]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic = committed_traffic(dim, deg, args.n) if world == 1 else None
 
+    # time-to-solution variant: the same steps with the block fast-diagonalisation preconditioner of the displacement system
+    variant = None
+    if fdm_variant:
+        try:
+            V = run_case(args, args.scaling, args.steps, args.warmup, rank, world, local_rank, torch, dist, rccl_ids, prec=pk.PREC_FDM, label="fdm")
+            variant = {"preconditioner_u": "block fast diagonalisation (PORO_PREC_FDM)", "ms_per_step": 1e3 * V["elapsed"] / args.steps,
+                       "cg_iterations_u": [[int(r[6]) for r in t] for t in V["traces"]], "DoF_updates_per_s": V["updates"] / V["elapsed"],
+                       "seconds_precondition_u": V["kernel_time"]["precondition_u_fdm"][0], "applications_precondition_u": V["kernel_time"]["precondition_u_fdm"][1],
+                       "seconds_alltoall": V["kernel_time"]["alltoall"][0]}
+        except RuntimeError as exc:           # a context that cannot use it (e.g. Dirichlet data not face-separable) says so; the headline stays valid
+            variant = {"error": str(exc)}
+    weak = None
+    if weak_line:
+        W = run_case(args, "weak", min(args.steps, 3), 1, rank, world, local_rank, torch, dist, rccl_ids, label="jacobi")
+        weak = {"value": W["updates"] / W["elapsed"], "ms_per_step": 1e3 * W["elapsed"] / min(args.steps, 3), "cells": "x".join(map(str, W["n"])), "N_u": W["n_u_glob"],
+                "cg_iterations_u": [[int(r[6]) for r in t] for t in W["traces"]]}
+
+    cg_u = [[int(r[6]) for r in t] for t in traces]
+    dead = [i for i, its in enumerate(cg_u) if not its or min(its) == 0]
     if rank == 0:
+        stop_txt = (f"recursive residual <= max(1e-12, {args.rel_tol:g}*||g_0||), g_0 = residual of the step's warm start (ReductionControl), cap {args.max_iter}" if args.stop == "reduction"
+                    else f"recursive residual <= max(1e-12, {args.rel_tol:g}*||b||), cap {args.max_iter}")
         out = {
             "metric": "DoF-updates/sec in assemble+SpMV per fixed-stress iter", "value": updates / elapsed, "unit": "DoF-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -225,20 +286,26 @@ def main():
             "config": {"workload": f"{dim}D Q{deg}/Q1 uniform box, {'x'.join(map(str, n))} cells, N_u={n_u_glob}, N_p={n_p_glob}; one time step = one fixed-stress iteration "
                                    f"(pressure loop + matrix-free Jacobi-PCG displacement solve + strain projection); input.data material/BCs, z-face BCs per SURVEY Q9",
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU", "operator": "matrix_free",
-                       "stopping_rule_u": f"recursive residual <= max(1e-12, {args.rel_tol:g}*||b||), cap {args.max_iter}"},
+                       "stopping_rule_u": stop_txt},
+            "cg_iterations_u": cg_u,
             "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e6 * avg_apply, "launches_timed": n_apply, "launches_enqueued": n_launched,
                          "note": ("operator kernel alone (as rocprofv3 reports it); inside PCG the Dirichlet dofs are inert (zero residual / direction), so no row fix-up runs "
                                   "(k_kron_fix_constrained only serves poro_apply_operator: %d launches in the timed region); "
-                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells) although the structured kernels read no index arrays") % n_fix},
+                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells) although the structured kernels read no index arrays; "
+                                  "traffic = PMC bytes per launch from profiles/r02_pmc_traffic.json, null unless that file was measured on this kernel source") % n_fix},
             "work_per_step": {k: work[k] / args.steps for k in work},
-            "kernel_only": {"apply_u_DoF_updates_per_s": (P.desc.n_dofs_u / (avg_apply + t_fix / max(n_fix, 1))) if n_apply else 0.0,
+            "kernel_only": {"apply_u_DoF_updates_per_s": (M["n_u_local"] / (avg_apply + t_fix / max(n_fix, 1))) if n_apply else 0.0,
                             "seconds_by_family": {k: v[0] for k, v in kernel_time.items()}, "launches_by_family": {k: v[1] for k, v in kernel_time.items()}},
             "fss_iterations_per_step": [int(len(t)) for t in traces],
         }
+        if variant is not None:
+            out["time_to_solution"] = {"jacobi_ms_per_step": out["ms_per_step"], "block_fdm": variant}
+        if weak is not None:
+            out["weak_scaling_line"] = weak
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dim, deg, args.cpu_n, args.rel_tol)
+            out["cpu_baseline"] = cpu_baseline(dim, deg, args.cpu_n, args.rel_tol, args.stop == "reduction")
         print(json.dumps(out), flush=True)
         if args.trace_out:
             # trace rows: [step, fss iteration, pressure iterations, inner pressure error, |p|_inf, error after displacement, u CG its, p CG its]
@@ -246,9 +313,12 @@ def main():
                     "cg_iterations_p": [int(r[7]) for r in t], "p_inf": float(t[-1][4]), "fss_error": float(t[-1][5]), "seconds": sec} for t, sec in zip(traces, step_seconds)]
             with open(args.trace_out, "w") as f:
                 json.dump({"workload": out["config"]["workload"], "n_gpus": world, "steps": rec, "seconds_total": elapsed}, f, indent=1)
-    R.close(); P.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
+    if dead:
+        # a timed step whose displacement solve accepted its warm start did no Krylov work: the line above is not a measurement of the hot path
+        print(f"bench.py: timed steps {dead} ran 0 displacement CG iterations", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -56,6 +56,8 @@ def load():
         L.oracle_proj_solve.argtypes = [C.c_void_p, C.c_int32] + slv
         L.oracle_get_volumetric_strain.argtypes = [C.c_void_p]
         L.oracle_noconvergence_count.argtypes = [C.c_void_p]
+        L.oracle_set_stop_rule.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_set_stop_rule.restype = None
         L.oracle_work_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
         L.oracle_work_counts.restype = None
         L.oracle_export_csr_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -118,8 +120,9 @@ class Oracle:
     def disp_assemble_system(self, rebuild=True):
         self.L.oracle_disp_assemble_system(self.ptr, int(rebuild))
 
-    def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_SSOR, omega=1.2):
+    def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_SSOR, omega=1.2, reduction=False):
         info = SolveInfo()
+        self.L.oracle_set_stop_rule(self.ptr, int(bool(reduction)))
         rc = self.L.oracle_disp_solve(self.ptr, abs_tol, rel_tol, max_iter, prec, omega, C.byref(info))
         return rc, info
 
@@ -190,10 +193,11 @@ class Oracle:
         self._cb = (ALLREDUCE_FN(_ar), SENDRECV_FN(_sr))
         self.L.oracle_set_comm(self.ptr, self._cb[0], self._cb[1], None)
 
-    def run(self, n_steps, p_init, dt, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50, abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_SSOR, coupled_fss=False, incremental_strain=False):
-        """PoroElasticProblem<dim>::run() restatement; returns (trace[rows,8], seconds_per_phase[4])."""
+    def run(self, n_steps, p_init, dt, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50, abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_SSOR, coupled_fss=False, incremental_strain=False, reduction=False):
+        """PoroElasticProblem<dim>::run() restatement; returns (trace[rows,8], seconds_per_phase[4]).  reduction: the displacement solve stops at
+        rel_u x its initial residual (PORO_STOP_REDUCTION) instead of rel_u x ||b||."""
         max_rows = 1 + n_steps * max_fss
         trace, tph = np.zeros((max_rows, 8)), np.zeros(4)
         rows = self.L.oracle_run(self.ptr, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec,
-                                 trace.ctypes.data_as(_dp), max_rows, tph.ctypes.data_as(_dp), int(bool(coupled_fss)) | (2 if incremental_strain else 0))
+                                 trace.ctypes.data_as(_dp), max_rows, tph.ctypes.data_as(_dp), int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0))
         return trace[:rows], tph

@@ -246,6 +246,7 @@ struct Oracle {
   Vec eps_v, eps_v0;
   int tensor_to_entry[9];
   int64_t work[6] = {0, 0, 0, 0, 0, 0};   // apply_u, apply_p, asm_rhs_u, residual_p, jacobian_p, proj_rhs (same units as the host driver's counters)
+  int stop_rule_u = 0;      // stopping rule of the displacement solve (see cg)
   int n_noconvergence = 0;  // SolverControl::NoConvergence would have been thrown this many times
 
   explicit Oracle(const poro_desc *dd) : d(*dd) {
@@ -414,7 +415,9 @@ struct Oracle {
 
   // SolverCG<>::solve with PreconditionSSOR (deal.II 8.4 semantics); prec: 0 none, 1 Jacobi, 2 SSOR(omega).
   // Multi-rank: the local matrix holds this slab's partial rows; shared-plane rows are completed by exchange_add.
-  SolveInfo cg(const Csr &M, Vec &x, const Vec &b, double abs_tol, double rel_tol, int max_iter, int prec, double omega, int64_t plane) {
+  // stop_rule 0: ||g|| <= max(abs_tol, rel_tol ||b||) (the reference's SolverControl objects); 1: rel_tol against the residual of the warm
+  // start (deal.II ReductionControl) - the stated rule of the transient benchmark, mirrored from include/poroel_hip.h PORO_STOP_REDUCTION
+  SolveInfo cg(const Csr &M, Vec &x, const Vec &b, double abs_tol, double rel_tol, int max_iter, int prec, double omega, int64_t plane, int stop_rule = 0) {
     const int64_t n = M.n; Vec g(n), dvec(n), h(n), diagv;
     SolveInfo info;
     int64_t &napply = work[&M == &A ? 0 : 1];
@@ -426,9 +429,9 @@ struct Oracle {
       else if (prec == 1) for (int64_t r = 0; r < n; ++r) y[r] = v[r] / diagv[r];
       else y = v;
     };
-    const double tol = std::max(abs_tol, rel_tol * std::sqrt(comm.dot(b, b, plane)));
     apply(g, x); for (int64_t i = 0; i < n; ++i) g[i] -= b[i];
     double res = std::sqrt(comm.dot(g, g, plane));
+    const double tol = std::max(abs_tol, rel_tol * (stop_rule == 1 ? res : std::sqrt(comm.dot(b, b, plane))));
     info.r0 = res; info.r = res;
     if (res <= tol) { info.converged = 1; return info; }
     precond(h, g); for (int64_t i = 0; i < n; ++i) dvec[i] = -h[i];
@@ -453,7 +456,7 @@ struct Oracle {
 
   // PoroElasticDisplacementSolver::solve :294-307
   SolveInfo disp_solve(double abs_tol, double rel_tol, int max_iter, int prec, double omega) {
-    SolveInfo s = cg(A, u, rhs_u, abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_u);
+    SolveInfo s = cg(A, u, rhs_u, abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_u, stop_rule_u);
     for (size_t i = 0; i < ddof.size(); ++i) u[ddof[i]] = dval[i];    // constraints.distribute :306
     return s;
   }
@@ -607,6 +610,7 @@ int oracle_proj_solve(oracle_ctx *c, int32_t entry, double abs_tol, double rel_t
   SolveInfo s = reinterpret_cast<Oracle *>(c)->proj_solve(entry, abs_tol, rel_tol, max_iter, prec, omega); fill_info(s, info); return s.converged ? 0 : 1;
 }
 void oracle_work_counts(oracle_ctx *c, int64_t *out, int reset) { Oracle *o = reinterpret_cast<Oracle *>(c); std::copy(o->work, o->work + 6, out); if (reset) std::fill(o->work, o->work + 6, 0); }
+void oracle_set_stop_rule(oracle_ctx *c, int rule) { reinterpret_cast<Oracle *>(c)->stop_rule_u = rule; }
 int oracle_noconvergence_count(oracle_ctx *c) { return reinterpret_cast<Oracle *>(c)->n_noconvergence; }
 int oracle_get_volumetric_strain(oracle_ctx *c) { reinterpret_cast<Oracle *>(c)->get_volumetric_strain(); return 0; }
 int oracle_export_csr_size(oracle_ctx *c, int which, int64_t *n, int64_t *nnz) {
@@ -695,8 +699,10 @@ void oracle_derived_parameters(double E, double nu, double alpha, double poro, d
 int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_tol, double pressure_tol, int max_fss, int max_pres,
                double abs_u, double rel_u, int max_it, int prec, double *trace, int max_rows, double *seconds_per_phase /*[4]: assemble_u, solve_u, projection, pressure*/,
                int coupled_fss /* bit 0: 0 = the reference (get_volumetric_strain() commented out at :399), 1 = that call restored: a real fixed-stress iteration;
-                                   bit 1: strain increment taken against the PREVIOUS step (eps_v^n) instead of the initial state (:317, :361-363) */) {
+                                   bit 1: strain increment taken against the PREVIOUS step (eps_v^n) instead of the initial state (:317, :361-363);
+                                   bit 2: displacement solve stops on the reduction of its initial residual (stop rule 1 of cg) */) {
   Oracle *o = reinterpret_cast<Oracle *>(c);
+  o->stop_rule_u = (coupled_fss & 4) ? 1 : 0;
   const int dim = o->dim; int rows = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tph[4] = {0, 0, 0, 0};

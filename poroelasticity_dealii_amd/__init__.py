@@ -15,6 +15,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 
 # ids of include/poroel_hip.h
 PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM, PREC_ILU0 = 0, 1, 2, 3, 4
+STOP_RHS, STOP_REDUCTION = 0, 1
 OP_CSR, OP_MATRIX_FREE = 0, 1
 MAT_A_U, MAT_MASS_P, MAT_LAPLACE_P, MAT_JACOBIAN_P = 0, 1, 2, 3
 VEC_U, VEC_RHS_U, VEC_P, VEC_P_OLD, VEC_DP, VEC_RESIDUAL_P, VEC_EPSV, VEC_EPSV0, VEC_SOURCE_P = range(9)
@@ -53,7 +54,8 @@ class Desc(C.Structure):
 
 
 class SolverOpts(C.Structure):
-    _fields_ = [("abs_tol", C.c_double), ("rel_tol", C.c_double), ("max_iter", C.c_int32), ("preconditioner", C.c_int32), ("omega", C.c_double)]
+    _fields_ = [("abs_tol", C.c_double), ("rel_tol", C.c_double), ("max_iter", C.c_int32), ("preconditioner", C.c_int32), ("omega", C.c_double),
+                ("stop_rule", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class SolveInfo(C.Structure):
@@ -83,7 +85,7 @@ HIP_SYMBOLS = [
     "poro_ctx_comm_init_callbacks", "poro_vec_set", "poro_vec_get", "poro_vec_fill", "poro_vec_copy", "poro_vec_axpy", "poro_vec_norm",
     "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_assemble_jacobian", "poro_pres_solve",
     "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain", "poro_get_effective_stresses",
-    "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_bench_operator", "poro_timers_reset", "poro_timers_enable", "poro_timers_get"]
+    "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_apply_preconditioner_u", "poro_bench_operator", "poro_timers_reset", "poro_timers_enable", "poro_timers_get"]
 
 _hip = None
 _host = None
@@ -129,6 +131,7 @@ def load_hip():
         L.poro_export_csr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), _ip, _dp]
         L.poro_apply_operator.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.poro_bench_operator.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
+        L.poro_apply_preconditioner_u.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, C.c_int32, _dp]
         L.poro_timers_reset.argtypes = [C.c_void_p]
         L.poro_timers_enable.argtypes = [C.c_void_p, C.c_int]
         L.poro_timers_get.argtypes = [C.c_void_p, C.c_char_p, _dp, C.POINTER(C.c_int64)]
@@ -282,16 +285,16 @@ class Context:
         self._chk(self.L.poro_disp_assemble_system(self.ptr, int(rebuild)))
 
     @staticmethod
-    def _opts(abs_tol, rel_tol, max_iter, prec, omega=1.0):
-        return SolverOpts(abs_tol, rel_tol, max_iter, prec, omega)
+    def _opts(abs_tol, rel_tol, max_iter, prec, omega=1.0, stop_rule=STOP_RHS):
+        return SolverOpts(abs_tol, rel_tol, max_iter, prec, omega, stop_rule, 0)
 
     def supports_preconditioner(self, which_system, prec):
         """which_system: 0 displacement, 1 pressure / projection."""
         return bool(self.L.poro_supports_preconditioner(self.ptr, which_system, prec))
 
-    def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_JACOBI, omega=1.2):
+    def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_JACOBI, omega=1.2, reduction=False):
         info = SolveInfo()
-        rc = self._chk(self.L.poro_disp_solve(self.ptr, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega)), C.byref(info)))
+        rc = self._chk(self.L.poro_disp_solve(self.ptr, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega, STOP_REDUCTION if reduction else STOP_RHS)), C.byref(info)))
         return rc, info
 
     def pres_assemble_residual(self, dt):
@@ -341,6 +344,14 @@ class Context:
         self._chk(self.L.poro_apply_operator(self.ptr, which, p, y.ctypes.data_as(_dp)))
         return y
 
+    def apply_preconditioner_u(self, prec, g, reps=0):
+        """z = P^-1 g with the displacement preconditioner; returns z (and the mean device seconds per application when reps > 0)"""
+        a, p = _arr_d(g)
+        z = np.empty_like(a)
+        t = C.c_double(0.0)
+        self._chk(self.L.poro_apply_preconditioner_u(self.ptr, prec, p, z.ctypes.data_as(_dp), reps, C.byref(t)))
+        return (z, t.value) if reps > 0 else z
+
     def bench_operator(self, operator_mode, reps):
         t = C.c_double()
         self._chk(self.L.poro_bench_operator(self.ptr, MAT_A_U, operator_mode, reps, C.byref(t)))
@@ -381,13 +392,13 @@ def rccl_unique_id():
 
 
 def run_problem(problem, n_steps, p_init, dt, device=0, operator_mode=OP_CSR, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
-                abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False):
+                abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False):
     """PoroElasticProblem<dim>::run() (PoroelasticityFSS.h:294-415) through the C++ host driver; returns (trace, Context)."""
     H = load_host()
     max_rows = 1 + n_steps * max_fss
     trace = np.zeros((max_rows, 8))
     ctx = C.c_void_p()
-    rows = H.poro_host_run(problem.handle, device, operator_mode, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0),
+    rows = H.poro_host_run(problem.handle, device, operator_mode, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0),
                            trace.ctypes.data_as(_dp), max_rows, C.byref(ctx))
     if rows < 0:
         raise RuntimeError(H.poro_host_last_error().decode())
@@ -401,10 +412,10 @@ class Runner:
     """Steppable PoroElasticProblem<dim> (C++ host driver): initialize() = PoroelasticityFSS.h:308-317, step() = one pass of :328-407."""
 
     def __init__(self, problem, device=0, operator_mode=OP_MATRIX_FREE, p_init=10e6, dt=60.0, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
-                 abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False):
+                 abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False):
         self.H = load_host()
         self.max_fss = max_fss
-        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0))
+        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0))
         if not h:
             raise RuntimeError(self.H.poro_host_last_error().decode())
         self.h = C.c_void_p(h)

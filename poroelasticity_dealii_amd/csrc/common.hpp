@@ -71,6 +71,11 @@ struct FdmDist {
   DevBuf<double> sendbuf, recvbuf, tz1, tz2; std::vector<double> hsend, hrecv;
 };
 
+// block fast diagonalisation of the displacement system (kernels_fdmu.hip): per (component, direction) the transform matrices S^T (fwd) and
+// S (bwd) in MFMA fragment order and the eigenvalues (inf marks removed modes); coef[c][d] = lambda + 2G (d == c) | G
+struct FdmuDir { int n = 0; DevBuf<double> fwd, bwd, lam; };
+struct FdmU { int dim = 0; int nn[3] = {1, 1, 1}; double coef[3][3] = {}; FdmuDir dir[3][3]; FdmuDir last_global[3]; bool built = false, single = false;
+              int fix[3][3][2] = {}; };
 // dependency levels of the lower / upper triangle in natural row order (rows of one level can be swept concurrently)
 struct SsorLevels { DevBuf<int32_t> fwd_rows, bwd_rows; std::vector<int64_t> fwd_off, bwd_off; bool built = false; };
 struct CsrDev {
@@ -130,13 +135,16 @@ struct poro_ctx {
   poro::DevBuf<double> ilu_u, ilu_J, ilu_M; bool ilu_u_valid = false, ilu_J_valid = false, ilu_M_valid = false;   // ILU(0) factors on the CSR patterns
   poro::DevBuf<double> wz_p;   // z = P^-1 g of an explicit preconditioner (pressure-sized systems)
   poro::FdmScalar fdm_p; poro::FdmDist fdm_dist; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
+  poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
+  std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
   int interleaved_u = 0;
+  int pcg_hint_fdm_u[2] = {0, 0};
   int pcg_hint_u[2] = {0, 0};   // iterations of the last two displacement solves (batch scheduling of the next one)
   int n_cus = 256; int mf_variant = 1 /* 0 element-matrix gather, 1 sum-factorised (where supported) */; int mask_anywhere = 0;
   // timing
-  bool timing = false; std::map<std::string, poro::Timer> timers;
+  bool timing = false; std::map<std::string, poro::Timer> timers; std::vector<hipEvent_t> event_pool;
   double jac_dt = -1;
 };
 
@@ -160,6 +168,7 @@ void la_pressure_tmp(hipStream_t s, double *t, const double *ev, const double *e
 void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, double a, double kappa, int64_t nnz);
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag);
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n);
+void la_pointwise_mul(hipStream_t s, double *y, const double *x, int64_t n);   // y *= x
 void la_xpby(hipStream_t s, double *y, double a, double b, const double *x, int64_t n);   // y = a y + b x
 void la_ilu_apply(hipStream_t s, const CsrDev &A, const double *lu, const SsorLevels &lv, const double *src, double *dst);
 void la_ssor_apply(hipStream_t s, const CsrDev &A, const double *val, const SsorLevels &lv, double omega, const double *src, double *dst);
@@ -173,7 +182,7 @@ void la_mask_zero(hipStream_t s, double *x, const uint8_t *mask, int64_t n);
 void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials);
 void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVec &diag, int prec, int64_t n, int64_t n_owned, double *partials /*2 sets: gg, gz*/);
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red);
-void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red /*bb, gg, gz*/, double abs_tol, double rel_tol, int max_iter);
+void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red /*bb, gg, gz*/, double abs_tol, double rel_tol, int max_iter, int stop_rule);
 // single-rank fast path: the consumers reduce the block partials themselves (no scalar kernels, no host round trip);
 // parity = iteration index & 1 selects the g.z slot read / written
 void pcg_update_g_fused(hipStream_t s, PcgScalars *sc, int parity, double *g, const double *h, const DiagVec &diag, int prec, int64_t n, int64_t n_owned,
@@ -209,6 +218,7 @@ void p_residual_stencil(hipStream_t s, int dim, const BoxDev &box, double kappa,
 
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);
+void kron_prepare_device();   // per-device function attributes (dynamic LDS opt-in) of the structured kernels; call after hipSetDevice
 BoxCoupling box_coupling(int dim, int k_u, const BoxDev &box);
 void box_rhs_u(hipStream_t s, int dim, const BoxCoupling &B, double alpha, const double *p, const double *lift, const double *neu, const uint8_t *mask, double *rhs);
 void box_asm_u_matrix(hipStream_t s, int dim, int k_u, const BoxDev &box, const double *Ke, const CsrDev &A, const uint8_t *mask, double *val);
@@ -217,6 +227,12 @@ void q1_eig(int n_cells, double h, std::vector<double> &S, std::vector<double> &
 void fdm_window(hipStream_t s, double *dst, const double *src, bool to_block, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid, int64_t grid_stride, int64_t grid_col0, int64_t grid_plane0);
 void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t n_outer, const double *in, double *out, const FdmScale *scale);
 void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], const double *g, double *z, double *t1, double *t2);
+// ---- kernels_fdmu.hip ---------------------------------------------------------------------------
+void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::vector<double> &S, std::vector<double> &lam);
+void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single);
+// stage 2: the whole application (single rank); 0 / 1: the passes of the leading directions before / after the caller's distributed last direction
+void fdmu_apply(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1, void *t2, int stage);
+void fdmu_lines(hipStream_t s, const FdmU &F, const FdmuDir *last_dir, int64_t C, int64_t col0, int64_t ncol_valid, void *in, void *out);
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
 int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                const PcgScalars *pcg = nullptr /* launch becomes a no-op once pcg->done / finishing is set */);   // returns the workgroup count (= partial slots used)

@@ -113,28 +113,34 @@ struct Rccl {
 
 // ---- timing -----------------------------------------------------------------------------------------------------
 // HIP events on the launch stream around every kernel family, drawn from a pool so a timed launch costs two
-// hipEventRecord calls; elapsed times are read back in bulk by timers_collect
-std::vector<hipEvent_t> g_event_pool;
-hipEvent_t event_get() {
-  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
-  hipEvent_t e; (void)hipEventCreate(&e); return e;
+// hipEventRecord calls; elapsed times are read back in bulk by timers_collect.  The pool belongs to the context (its device, its host thread).
+hipEvent_t event_get(poro_ctx *c) {
+  if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+  hipEvent_t e; PORO_HIP(hipEventCreate(&e)); return e;
 }
 struct Timed {
   poro_ctx *c; Timer *t = nullptr; hipEvent_t a = nullptr, b = nullptr;
   Timed(poro_ctx *c_, const char *name) : c(c_) {
     if (!c->timing) return;
     t = &c->timers[name];
-    a = event_get(); b = event_get(); (void)hipEventRecord(a, c->stream);
+    a = event_get(c); b = event_get(c); (void)hipEventRecord(a, c->stream);
   }
   ~Timed() { if (!t) return; (void)hipEventRecord(b, c->stream); t->pending.emplace_back(a, b); t->launches++; }
 };
 void timers_collect(poro_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->timers) {
-    for (auto &p : kv.second.pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.first, p.second); kv.second.seconds += ms * 1e-3; g_event_pool.push_back(p.first); g_event_pool.push_back(p.second); }
+    for (auto &p : kv.second.pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.first, p.second); kv.second.seconds += ms * 1e-3; c->event_pool.push_back(p.first); c->event_pool.push_back(p.second); }
     kv.second.pending.clear();
   }
 }
+// a start / stop event pair that is returned to the context's pool on every exit path
+struct EventPair {
+  poro_ctx *c; hipEvent_t e0, e1;
+  explicit EventPair(poro_ctx *c_) : c(c_), e0(event_get(c_)), e1(event_get(c_)) {}
+  ~EventPair() { c->event_pool.push_back(e0); c->event_pool.push_back(e1); }
+  EventPair(const EventPair &) = delete; EventPair &operator=(const EventPair &) = delete;
+};
 
 // ---- communication: sum the neighbour's partial rows on the shared node planes; all-reduce scalars -------------------
 void exchange_add(poro_ctx *c, double *v, int64_t n, int64_t plane) {
@@ -190,7 +196,7 @@ MfArgs mf_args(poro_ctx *c) {
 }
 // y = A_u x without forming A_u: sum-factorised sweeps where available, element-matrix gather otherwise
 void mf_operator(poro_ctx *c, const double *x, double *y, bool constrained) {
-  if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) { const int slots = kron_apply(c->stream, mf_args(c), x, y, constrained, c->n_cus); if (constrained) kron_fix_constrained(c->stream, mf_args(c), x, y, nullptr, slots); }
+  if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) { const int slots = kron_apply(c->stream, mf_args(c), x, y, constrained, c->n_cus); if (constrained) kron_fix_constrained(c->stream, mf_args(c), x, y, nullptr, std::abs(slots)); }
   else mf_apply(c->stream, mf_args(c), x, y, constrained);
 }
 
@@ -209,13 +215,13 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
   if (mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
     int slots;
     if (c->timing) {   // events attached to the dispatch itself: the kernel's own duration, without the gaps to its neighbours in the stream
-      Timer &t = c->timers["apply_u_matrix_free"]; hipEvent_t e0 = event_get(), e1 = event_get();
+      Timer &t = c->timers["apply_u_matrix_free"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
       slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials, e0, e1, pcg_state);
       t.pending.emplace_back(e0, e1); t.launches++;
     } else slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials, nullptr, nullptr, pcg_state);
     // inside PCG the Dirichlet rows are inert (zero residual and direction), so what the structured kernel leaves there is never read
-    if (fix_rows) { Timed tm(c, "apply_u_dirichlet_rows"); kron_fix_constrained(c->stream, mf_args(c), x, y, dot_partials, slots); }
-    fused = dot_partials != nullptr;
+    fused = dot_partials != nullptr && slots > 0;   // slots < 0: too many workgroups for the partial slots, the kernel ran without the fused x.y
+    if (fix_rows) { Timed tm(c, "apply_u_dirichlet_rows"); kron_fix_constrained(c->stream, mf_args(c), x, y, fused ? dot_partials : nullptr, slots > 0 ? slots : -slots); }
   } else {
     Timed tm(c, mode == PORO_OP_MATRIX_FREE ? "apply_u_matrix_free" : "apply_u_csr");
     if (mode == PORO_OP_MATRIX_FREE) { mf_apply(c->stream, mf_args(c), x, y, true, dot_partials); fused = dot_partials != nullptr; }
@@ -241,7 +247,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   const bool multi = c->comm.multi();
   double *part = c->partials.p, *red = c->red.p; PcgScalars *sc = c->scal.p;
   double *part_dh = part + 3 * (size_t)kMaxPartials;      // slots of the fused / separate d.h partials
-  hipEvent_t e0, e1; PORO_HIP(hipEventCreate(&e0)); PORO_HIP(hipEventCreate(&e1)); PORO_HIP(hipEventRecord(e0, s));
+  EventPair ev(c); const hipEvent_t e0 = ev.e0, e1 = ev.e1; PORO_HIP(hipEventRecord(e0, s));
   int64_t applies = 0;
   // g = A x - b ; d = -P^-1 g ; gh = g.P^-1 g
   apply(x, h, nullptr); ++applies;
@@ -251,7 +257,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
   pcg_scalars_sum(s, part, 3, red);
   allreduce_sum(c, red, 3);
-  pcg_scalars_start(s, sc, red, opts->abs_tol, opts->rel_tol, opts->max_iter);
+  pcg_scalars_start(s, sc, red, opts->abs_tol, opts->rel_tol, opts->max_iter, opts->stop_rule);
   PORO_HIP(hipMemsetAsync(part_dh, 0, kMaxPartials * sizeof(double), s));
   PcgScalars hs{};
   int batch = precond ? 1 : 4, it = 0;   // an explicit preconditioner is expensive and strong: poll after every iteration at first
@@ -283,7 +289,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   }
   if (its_hint) { its_hint[1] = its_hint[0]; its_hint[0] = hs.it; }
   PORO_HIP(hipEventRecord(e1, s)); PORO_HIP(hipEventSynchronize(e1));
-  float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (info) { info->iterations = hs.it; info->converged = hs.converged; info->initial_residual = hs.res0; info->final_residual = hs.res; info->seconds = ms * 1e-3;
               info->operator_applications = hs.it + 1;   // initial residual + one per iteration (launches enqueued behind the finishing iteration are no-ops and are not counted)
               (void)applies; }
@@ -323,11 +329,11 @@ int pcg_host(poro_ctx *c, int64_t n, int64_t n_own, const std::function<void(con
              double *x, const double *b, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info) {
   hipStream_t s = c->stream;
   const auto t0 = std::chrono::steady_clock::now();
-  const double tol = std::max(opts->abs_tol, opts->rel_tol * std::sqrt(dot_host(c, b, b, n_own)));
   int64_t applies = 0; int it = 0, conv = 0;
   apply(x, g); ++applies;
   la_axpy(s, g, -1.0, b, n);                                     // g = A x - b
   double res = std::sqrt(dot_host(c, g, g, n_own)); const double res0 = res;
+  const double tol = std::max(opts->abs_tol, opts->rel_tol * (opts->stop_rule == PORO_STOP_REDUCTION ? res0 : std::sqrt(dot_host(c, b, b, n_own))));
   if (res <= tol) conv = 1;
   else {
     precond(g, h);
@@ -493,6 +499,68 @@ void fdm_precondition_p(poro_ctx *c, double a, const double k[3], const double *
   else fdm_transform(s, L.dir[0].S.p, n0, 1, nl, t1, z, nullptr);
 }
 
+// ---- block fast diagonalisation of the displacement system (kernels_fdmu.hip) ---------------------------------------------------------
+// Usable when the box is node-interleaved and, per component, the Dirichlet dofs are exactly a union of whole faces (then the 1D matrices
+// of that component just lose their end nodes) with at least one face each (otherwise the block is singular).
+void analyse_fdm_u(poro_ctx *c) {
+  if (c->fdm_u_state != 0) return;
+  c->fdm_u_state = -1;
+  if (!c->box.enabled || !c->interleaved_u) { c->fdm_u_why = "needs a uniform box with node-interleaved displacement dofs"; return; }
+  if (c->comm.multi()) { c->fdm_u_why = "PORO_PREC_FDM for the displacement system is implemented for one rank"; return; }
+  const int dim = c->dim; const int64_t nn[3] = {c->box.nn[0], c->box.nn[1], dim == 3 ? c->box.nn[2] : 1};
+  for (int d = 0; d < dim; ++d) if (nn[d] > 320) { c->fdm_u_why = "more than 320 nodes per grid line"; return; }
+  const std::vector<uint8_t> &nm = c->h_node_mask;
+  auto node = [&](int64_t i, int64_t j, int64_t k) { return (k * nn[1] + j) * nn[0] + i; };
+  FdmU &F = c->fdm_u;
+  for (int comp = 0; comp < dim; ++comp) {
+    bool any = false;
+    for (int d = 0; d < dim; ++d) for (int side = 0; side < 2; ++side) {
+      bool all = true;
+      const int64_t fixed = side ? nn[d] - 1 : 0;
+      const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+      for (int64_t a = 0; a < nn[d1] && all; ++a) for (int64_t b = 0; b < nn[d2]; ++b) {
+        int64_t ix[3]; ix[d] = fixed; ix[d1] = a; ix[d2] = b;
+        if (!(nm[node(ix[0], ix[1], ix[2])] >> comp & 1)) { all = false; break; }
+      }
+      F.fix[comp][d][side] = all ? 1 : 0; any = any || all;
+    }
+    if (!any) { c->fdm_u_why = "a displacement component without a constrained face (singular block)"; return; }
+    for (int64_t k = 0; k < nn[2]; ++k) for (int64_t j = 0; j < nn[1]; ++j) for (int64_t i = 0; i < nn[0]; ++i) {
+      const int64_t ix[3] = {i, j, k}; bool on = false;
+      for (int d = 0; d < dim; ++d) on = on || (ix[d] == 0 && F.fix[comp][d][0]) || (ix[d] == nn[d] - 1 && F.fix[comp][d][1]);
+      if (on != (bool)(nm[node(i, j, k)] >> comp & 1)) { c->fdm_u_why = "Dirichlet dofs are not a union of whole faces per component"; return; }
+    }
+  }
+  c->fdm_u_state = 1;
+}
+void build_fdm_u(poro_ctx *c) {
+  FdmU &F = c->fdm_u;
+  if (F.built) return;
+  analyse_fdm_u(c);
+  if (c->fdm_u_state != 1) throw Error("PORO_PREC_FDM (displacement): " + c->fdm_u_why);
+  const int dim = c->dim;
+  F.dim = dim; F.single = std::getenv("PORO_FDMU_SINGLE") != nullptr;   // fp32 transforms (experimental switch)
+  for (int d = 0; d < 3; ++d) F.nn[d] = d < dim ? c->box.nn[d] : 1;
+  const double l2g = c->mat.lame_lambda + 2 * c->mat.shear_G, G = c->mat.shear_G;
+  for (int comp = 0; comp < dim; ++comp) for (int d = 0; d < dim; ++d) F.coef[comp][d] = d == comp ? l2g : G;
+  // eigenpairs per (direction, end conditions); components with the same end conditions share the host work
+  for (int d = 0; d < dim; ++d) {
+    std::vector<double> S[4], lam[4]; bool have[4] = {false, false, false, false};
+    for (int comp = 0; comp < dim; ++comp) {
+      const int key = F.fix[comp][d][0] * 2 + F.fix[comp][d][1];
+      if (!have[key]) { fdmu_eig_1d(c->k_u, c->box.n[d], c->box.h[d], F.fix[comp][d][0], F.fix[comp][d][1], S[key], lam[key]); have[key] = true; }
+      fdmu_upload_dir(F.dir[comp][d], S[key], lam[key], F.nn[d], F.single);
+    }
+  }
+  c->fdmu_t1.alloc(c->n_u); c->fdmu_t2.alloc(c->n_u);
+  if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
+  F.built = true;
+}
+void fdm_precondition_u(poro_ctx *c, const double *g, double *z) {
+  Timed tm(c, "precondition_u_fdm");
+  fdmu_apply(c->stream, c->fdm_u, g, z, c->fdmu_t1.p, c->fdmu_t2.p, 2);
+}
+
 void setup(poro_ctx *c, const poro_desc *d) {
   if (d->abi_version != PORO_ABI_VERSION) throw Error("poro_desc.abi_version mismatch");
   if (d->dim != 2 && d->dim != 3) throw Error("dim must be 2 or 3");
@@ -556,7 +624,7 @@ void setup(poro_ctx *c, const poro_desc *d) {
   { std::vector<uint8_t> m(c->n_u, 0); std::vector<double> v(c->n_u, 0.0);
     for (int64_t i = 0; i < d->n_dirichlet; ++i) { const int32_t dof = d->dirichlet_dof[i]; if (dof < 0 || dof >= c->n_u) throw Error("dirichlet_dof out of range"); m[dof] = 1; v[dof] = d->dirichlet_value[i]; }
     c->dir_mask.upload(m); c->dir_val.upload(v);
-    { std::vector<uint8_t> nm((size_t)(c->n_u / c->dim), 0); for (int64_t i = 0; i < d->n_dirichlet; ++i) nm[d->dirichlet_dof[i] / c->dim] |= (uint8_t)(1u << (d->dirichlet_dof[i] % c->dim)); c->node_mask.upload(nm); }
+    { std::vector<uint8_t> nm((size_t)(c->n_u / c->dim), 0); for (int64_t i = 0; i < d->n_dirichlet; ++i) nm[d->dirichlet_dof[i] / c->dim] |= (uint8_t)(1u << (d->dirichlet_dof[i] % c->dim)); c->node_mask.upload(nm); c->h_node_mask = std::move(nm); }
     if (d->n_dirichlet) c->dir_dofs.upload(d->dirichlet_dof, d->n_dirichlet);
     if (d->box.enabled) {   // are all constrained dofs on the box boundary?  (lets the matrix-free kernels skip mask loads in the interior)
       int64_t nn[3] = {1, 1, 1}; for (int k = 0; k < c->dim; ++k) nn[k] = (int64_t)c->k_u * d->box.n[k] + 1;
@@ -659,6 +727,7 @@ int poro_ctx_create(const poro_desc *desc, int device, int operator_mode, poro_c
     std::unique_ptr<poro_ctx> c(new poro_ctx());
     c->device = device; c->operator_mode = operator_mode;
     PORO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    kron_prepare_device();   // function attributes are per device: opt in to the large dynamic LDS on THIS one
     setup(c.get(), desc);
     *out = c.release();
     return 0;
@@ -669,6 +738,8 @@ void poro_ctx_destroy(poro_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   timers_collect(c);
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  c->event_pool.clear();
   if (c->comm.nccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->comm.nccl_comm);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -854,7 +925,8 @@ int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec
   if (!c) return 0;
   if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
   if (prec == PORO_PREC_SSOR || prec == PORO_PREC_ILU0) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
-  if (prec == PORO_PREC_FDM) return which_system == 1 && fdm_p_supported(c);
+  if (prec == PORO_PREC_FDM && which_system == 1) return fdm_p_supported(c);
+  if (prec == PORO_PREC_FDM) { analyse_fdm_u(c); return c->fdm_u_state == 1; }
   return 0;
 }
 int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *info) {
@@ -862,7 +934,6 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     PORO_HIP(hipSetDevice(c->device));
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
-    if (opts->preconditioner == PORO_PREC_FDM) throw Error("PORO_PREC_FDM is implemented for the pressure / projection systems (poro_supports_preconditioner)");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       if (mode != PORO_OP_CSR) throw Error("PORO_PREC_ILU0 needs the assembled CSR operator");
       const int rc = pcg_ilu0(c, c->Au, c->Au_val.p, c->ilu_u, c->ilu_u_valid, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
@@ -878,6 +949,16 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       return rc;
     }
     auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp, false, dp ? c->scal.p : nullptr); };
+    if (opts->preconditioner == PORO_PREC_FDM) {
+      // z = blockdiag(A_cc)^-1 g by fast diagonalisation: the same device-controlled SolverCG recurrence with an explicit preconditioner vector
+      build_fdm_u(c);
+      const std::function<void(const double *, double *)> P = [&](const double *g, double *z) { fdm_precondition_u(c, g, z); };
+      DiagVec dz; dz.full = c->dinv_u.p; dz.ncomp = c->dim; dz.inert = c->dir_mask.p; dz.z = c->wz_u.p;
+      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_fdm_u);
+      la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
+      PORO_HIP(hipStreamSynchronize(c->stream));
+      return rc;
+    }
     DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim; dv.inert = c->dir_mask.p;
     if (c->diag_u_cls.p) { dv.cls = c->diag_u_cls.p; dv.tab = c->diag_u_tab.p; }
     const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dv, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, nullptr, c->pcg_hint_u);
@@ -1072,6 +1153,28 @@ int poro_apply_operator(poro_ctx *c, int which, const double *x_host, double *y_
   });
 }
 
+int poro_apply_preconditioner_u(poro_ctx *c, int32_t preconditioner, const double *g_host, double *z_host, int32_t reps, double *seconds_per_apply) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device)); hipStream_t s = c->stream;
+    if (!c->matrix_built) throw Error("apply_preconditioner_u before disp_assemble_system");
+    DevBuf<double> g, z; g.upload(g_host, c->n_u); z.alloc(c->n_u); z.zero(s);
+    if (preconditioner == PORO_PREC_FDM) {
+      build_fdm_u(c);
+      fdm_precondition_u(c, g.p, z.p);
+      if (reps > 0 && seconds_per_apply) {
+        EventPair ev(c); PORO_HIP(hipEventRecord(ev.e0, s));
+        for (int k = 0; k < reps; ++k) fdm_precondition_u(c, g.p, z.p);
+        PORO_HIP(hipEventRecord(ev.e1, s)); PORO_HIP(hipEventSynchronize(ev.e1));
+        float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1)); *seconds_per_apply = ms * 1e-3 / reps;
+      }
+    } else if (preconditioner == PORO_PREC_JACOBI) {
+      PORO_HIP(hipMemcpyAsync(z.p, g.p, c->n_u * sizeof(double), hipMemcpyDeviceToDevice, s));
+      la_pointwise_mul(s, z.p, c->dinv_u.p, c->n_u);
+    } else throw Error("apply_preconditioner_u: PORO_PREC_JACOBI or PORO_PREC_FDM");
+    PORO_HIP(hipMemcpyAsync(z_host, z.p, c->n_u * sizeof(double), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s)); return 0;
+  });
+}
+
 int poro_bench_operator(poro_ctx *c, int which, int operator_mode, int reps, double *seconds_per_apply) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device)); hipStream_t s = c->stream;
@@ -1081,11 +1184,11 @@ int poro_bench_operator(poro_ctx *c, int which, int operator_mode, int reps, dou
     std::vector<double> hx(c->n_u); for (int64_t i = 0; i < c->n_u; ++i) hx[i] = std::sin(0.37 * (double)i);   // SURVEY 8d synthetic vector
     DevBuf<double> x, y; x.upload(hx); y.alloc(c->n_u);
     for (int k = 0; k < 3; ++k) apply_A_u(c, x.p, y.p, operator_mode);
-    hipEvent_t e0, e1; PORO_HIP(hipEventCreate(&e0)); PORO_HIP(hipEventCreate(&e1));
+    EventPair ev(c); const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     PORO_HIP(hipEventRecord(e0, s));
     for (int k = 0; k < reps; ++k) apply_A_u(c, x.p, y.p, operator_mode);
     PORO_HIP(hipEventRecord(e1, s)); PORO_HIP(hipEventSynchronize(e1));
-    float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, e0, e1));
     *seconds_per_apply = ms * 1e-3 / reps; return 0;
   });
 }

@@ -1,0 +1,382 @@
+// Block fast-diagonalisation preconditioner of the DISPLACEMENT system (K-prec, SURVEY 8f-1 "a stronger preconditioner") on uniform
+// boxes (gfx950, wave64, fp64 / fp32 MFMA).
+//
+// On a box the diagonal blocks of A_u (PoroElasticDisplacementSolver.h:230-242, one block per displacement component c) are
+//   A_cc = sum_d coef(c,d) (K_d in direction d) (x) (M_e in the other directions),   coef = lambda + 2G (d == c) | G (d != c),
+// with the 1D FE_Q(k_u) mass / stiffness matrices M_d, K_d; a Dirichlet condition on component c over a whole face removes the end
+// node of that direction from the 1D matrices of component c, so the structure survives the constraints.  With the generalised 1D
+// eigen-decompositions K S = M S Lambda, S^T M S = I (host, once per mesh; one set per component because the end conditions differ)
+//   A_cc^-1 = (Sx (x) Sy (x) Sz) diag(sum_d coef(c,d) lam_d)^-1 (Sx (x) Sy (x) Sz)^T   EXACTLY.
+// z = blockdiag(A_cc)^-1 g is spectrally equivalent to A_u^-1 (Korn): CG needs ~20 iterations independent of h instead of O(1/h)
+// with Jacobi (245 at BASELINE config 4).  The off-diagonal blocks A_ab (products of first-derivative matrices) are not separable and
+// stay in the Krylov iteration.
+//
+// One application = 2 dim dense (n_d x n_d) transforms along the grid lines of a [component][z][y][x] array: GEMM-shaped work
+// (2 x 3 x 6 x 145^4 = 1.6e10 flop at config 4), so it runs on the matrix cores.  One kernel serves every pass:
+//   load a panel of 32 grid lines (all points of each line) into LDS -> D = T1 * panel on v_mfma_f64_16x16x4_f64 (T as the A operand,
+//   streamed from L2 in MFMA fragment order, 512 contiguous bytes per wave and k-step; panel columns as the B operand from LDS)
+//   -> [last direction only: scale by the inverse eigenvalue sums, write back to LDS, second GEMM with T2 = S] -> LDS -> coalesced store.
+// The first pass reads the node-interleaved residual (dof = node * dim + c), the last pass writes the interleaved z; in between the
+// data are component-planar.  Passes: x, y, z (forward + scaling + backward fused), y, x  = 5 sweeps over the vector in 3D.
+// Rows / columns of constrained end nodes are zero in S, so z = 0 on Dirichlet dofs (they are inert inside PCG anyway).
+#include "common.hpp"
+#include <cmath>
+#include <limits>
+
+namespace poro {
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <class T> struct Mfma;
+template <> struct Mfma<double> { typedef v4d acc_t; static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); } };
+template <> struct Mfma<float> { typedef v4f acc_t; static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); } };
+
+constexpr int kNT = 32;        // grid lines per panel (two 16-column MFMA tiles)
+constexpr int kLdK = kNT + 16; // LDS row stride of a [k][line] panel: the four k-rows of a B fragment land in disjoint banks
+constexpr int kThreads = 256;  // 4 waves: wave w owns column tile w & 1 and the output row tiles of half w >> 1
+
+struct FdmuPass {
+  int nK;               // points per line (= output rows)
+  int MT, KK;           // 16-row output tiles, 4-deep k-steps (both ceil)
+  int64_t SI;           // element stride along the line: 1 (x), nx (y), nx ny (z)
+  int64_t n_lines;      // lines per component
+  int64_t comp_stride;  // planar arrays: elements per component
+  int ncomp;
+  int in_interleaved, out_interleaved;   // array layout: element (line point e, component c) at e * ncomp + c instead of c * comp_stride + e
+  int x_layout;         // 1: LDS panel stored [line][k] (contiguous lines: the x direction), 0: [k][line]
+  int ld_line;          // x_layout: LDS stride between lines
+  // fused scaling (last direction): D(m, line) /= kd * lam_d[m] + k0 * lam0[i] + k1 * lam1[j], (i, j) = grid position of the line
+  int fused; int n0; int64_t col0, col_total; double kd[3], k0[3], k1[3];
+  const void *T1[3], *T2[3];             // per component: transform matrices in MFMA fragment order [MT][KK][64]
+  const double *lam_d[3], *lam0[3], *lam1[3];
+};
+
+// element index of point k of line n inside one component's grid
+__device__ __forceinline__ int64_t line_base(const FdmuPass &P, int64_t n) { const int64_t o = n / P.SI; return o * P.SI * P.nK + (n - o * P.SI); }
+
+template <class TC, class TIn, class TOut, int MTH>
+__global__ void __launch_bounds__(kThreads)
+k_fdmu_pass(FdmuPass P, const TIn *__restrict__ in, TOut *__restrict__ out) {
+  extern __shared__ double lds_raw[];
+  TC *L = reinterpret_cast<TC *>(lds_raw);
+  typedef typename Mfma<TC>::acc_t acc_t;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = blockIdx.y;
+  const int64_t n0 = (int64_t)blockIdx.x * kNT;
+  const int rows = P.KK * 4 > P.MT * 16 ? P.KK * 4 : P.MT * 16;      // panel rows: k (input) or m (output), zero padded
+  const int s_n = P.x_layout ? P.ld_line : 1, s_k = P.x_layout ? 1 : kLdK;
+
+  // ---- load the panel: element (k, line) -> L[line * s_n + k * s_k]; padded rows and lines are zero ----
+  if (P.x_layout) {
+    // lines are contiguous in memory (planar) or ncomp-strided (interleaved): run along k
+    const int total = kNT * rows;
+    for (int idx = tid; idx < total; idx += kThreads) {
+      const int ln = idx / rows, k = idx - ln * rows;
+      const int64_t n = n0 + ln;
+      TC v = 0;
+      if (k < P.nK && n < P.n_lines) {
+        const int64_t e = n * P.nK + k;
+        v = (TC)(P.in_interleaved ? in[e * P.ncomp + c] : in[(int64_t)c * P.comp_stride + e]);
+      }
+      L[ln * s_n + k] = v;
+    }
+  } else {
+    const int ln = tid & (kNT - 1);
+    const int64_t n = n0 + ln;
+    const bool lv = n < P.n_lines;
+    const int64_t base = (int64_t)c * P.comp_stride + (lv ? line_base(P, n) : 0);
+    for (int k = tid / kNT; k < rows; k += kThreads / kNT) L[k * kLdK + ln] = (lv && k < P.nK) ? (TC)in[base + (int64_t)k * P.SI] : (TC)0;
+  }
+  __syncthreads();
+
+  const int nt = w & 1, mh = w >> 1;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const TC *Bp = L + (nt * 16 + i16) * s_n + kq * s_k;       // B fragment of k-step kk: Bp[4 kk s_k]
+  acc_t acc[MTH];
+
+  auto gemm = [&](const TC *__restrict__ Tf) {
+#pragma unroll
+    for (int t = 0; t < MTH; ++t) acc[t] = acc_t{0, 0, 0, 0};
+    const TC *Ap = Tf + ((int64_t)(mh * MTH) * P.KK) * 64 + lane;   // fragment (m-tile, kk) at ((mt * KK) + kk) * 64 + lane
+    int kk = 0;
+    for (; kk + 4 <= P.KK; kk += 4) {          // 4 k-steps per trip, every operand load issued before the first MFMA
+      TC a[4][MTH], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        b[u] = Bp[(kk + u) * 4 * s_k];
+#pragma unroll
+        for (int t = 0; t < MTH; ++t) a[u][t] = (mh * MTH + t < P.MT) ? Ap[((int64_t)t * P.KK + kk + u) * 64] : (TC)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < MTH; ++t) acc[t] = Mfma<TC>::run(a[u][t], b[u], acc[t]);
+    }
+    for (; kk < P.KK; ++kk) {
+      const TC b = Bp[kk * 4 * s_k];
+#pragma unroll
+      for (int t = 0; t < MTH; ++t) { const TC a = (mh * MTH + t < P.MT) ? Ap[((int64_t)t * P.KK + kk) * 64] : (TC)0; acc[t] = Mfma<TC>::run(a, b, acc[t]); }
+    }
+  };
+  // D fragment -> LDS: register q of a lane holds row (lane >> 4) + 4 q of the tile, column lane & 15
+  auto acc_to_lds = [&](bool scale) {
+    double base = 0; bool lvalid = true;
+    if (scale) {
+      const int64_t col = P.col0 + n0 + nt * 16 + i16;           // global line index = (j, i) grid position
+      lvalid = n0 + nt * 16 + i16 < P.n_lines && col < P.col_total;
+      if (lvalid) {
+        if (P.lam1[c]) { const int64_t j = col / P.n0; base = P.k0[c] * P.lam0[c][col - j * P.n0] + P.k1[c] * P.lam1[c][j]; }
+        else if (P.lam0[c]) base = P.k0[c] * P.lam0[c][col];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < MTH; ++t) {
+      const int mt = mh * MTH + t;
+      if (mt >= P.MT) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = mt * 16 + kq + 4 * q;
+        double v = (double)acc[t][q];
+        if (scale) v = (lvalid && m < P.nK) ? v / (base + P.kd[c] * P.lam_d[c][m]) : 0.0;   // padded / constrained modes carry lam = inf
+        L[(nt * 16 + i16) * s_n + m * s_k] = (TC)v;
+      }
+    }
+  };
+
+  gemm(reinterpret_cast<const TC *>(P.T1[c]));
+  __syncthreads();                       // everybody has finished reading the input panel
+  acc_to_lds(P.fused != 0);
+  if (P.fused) {
+    // rows >= 16 MT of the panel still hold input data; the second GEMM's k runs to 4 KK <= rows: clear what the first result did not cover
+    for (int idx = tid; idx < (rows - P.MT * 16) * kNT; idx += kThreads) { const int k = P.MT * 16 + idx / kNT, ln = idx % kNT; L[ln * s_n + k * s_k] = 0; }
+    __syncthreads();
+    gemm(reinterpret_cast<const TC *>(P.T2[c]));
+    __syncthreads();
+    acc_to_lds(false);
+  }
+  __syncthreads();
+
+  // ---- store the panel (rows m < nK) ----
+  if (P.x_layout) {
+    const int total = kNT * P.nK;
+    for (int idx = tid; idx < total; idx += kThreads) {
+      const int ln = idx / P.nK, m = idx - ln * P.nK;
+      const int64_t n = n0 + ln;
+      if (n >= P.n_lines) continue;
+      const int64_t e = n * P.nK + m;
+      const TC v = L[ln * s_n + m];
+      if (P.out_interleaved) out[e * P.ncomp + c] = (TOut)v; else out[(int64_t)c * P.comp_stride + e] = (TOut)v;
+    }
+  } else {
+    const int ln = tid & (kNT - 1);
+    const int64_t n = n0 + ln;
+    if (n < P.n_lines) {
+      const int64_t base = (int64_t)c * P.comp_stride + line_base(P, n);
+      for (int m = tid / kNT; m < P.nK; m += kThreads / kNT) out[base + (int64_t)m * P.SI] = (TOut)L[m * kLdK + ln];
+    }
+  }
+}
+
+template <class TC, class TIn, class TOut>
+void launch_pass(hipStream_t s, const FdmuPass &P, const TIn *in, TOut *out) {
+  const int rows = std::max(P.KK * 4, P.MT * 16);
+  const size_t lds = sizeof(TC) * (size_t)(P.x_layout ? kNT * P.ld_line : rows * kLdK);
+  const dim3 grid((unsigned)((P.n_lines + kNT - 1) / kNT), (unsigned)P.ncomp);
+  const int mth = (P.MT + 1) / 2;
+#define PORO_FDMU_CASE(M)                                                                                                          \
+  { static bool set_##M[64] = {false}; int dev = 0; (void)hipGetDevice(&dev);                                                    \
+    if (dev < 64 && !set_##M[dev]) { PORO_HIP(hipFuncSetAttribute((const void *)k_fdmu_pass<TC, TIn, TOut, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set_##M[dev] = true; } \
+    hipLaunchKernelGGL((k_fdmu_pass<TC, TIn, TOut, M>), grid, dim3(kThreads), lds, s, P, in, out); }
+  if (mth <= 1) PORO_FDMU_CASE(1)
+  else if (mth <= 2) PORO_FDMU_CASE(2)
+  else if (mth <= 3) PORO_FDMU_CASE(3)
+  else if (mth <= 5) PORO_FDMU_CASE(5)
+  else if (mth <= 7) PORO_FDMU_CASE(7)
+  else if (mth <= 10) PORO_FDMU_CASE(10)
+  else throw Error("fast diagonalisation of the displacement system: more than 320 nodes per grid line");
+#undef PORO_FDMU_CASE
+}
+
+// ---- host: 1D matrices, generalised eigen-decomposition ------------------------------------------------------------------------
+// symmetric eigenproblem by cyclic Jacobi rotations (n <= 320: a few 1e8 flop, once per mesh); V's columns are the eigenvectors
+void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &V, std::vector<double> &w) {
+  V.assign((size_t)n * n, 0.0); for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < n; ++i) { diag += A[(size_t)i * n + i] * A[(size_t)i * n + i]; for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j]; }
+    if (off <= 1e-30 * diag || off == 0) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < n; ++k) {   // columns p, q
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = cs * akp - sn * akq; A[(size_t)k * n + q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < n; ++k) {   // rows p, q
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = cs * apk - sn * aqk; A[(size_t)q * n + k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = cs * vkp - sn * vkq; V[(size_t)k * n + q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  w.resize(n); for (int i = 0; i < n; ++i) w[i] = A[(size_t)i * n + i];
+}
+
+// FE_Q(k) mass / stiffness matrices of n_cells cells of length h (dense, nn = k n_cells + 1); element matrices as in kernels_kron.hip
+void fe1d(int k, int n_cells, double h, std::vector<double> &M, std::vector<double> &K) {
+  const int nn = k * n_cells + 1; M.assign((size_t)nn * nn, 0.0); K.assign((size_t)nn * nn, 0.0);
+  static const double M2[3][3] = {{4, 2, -1}, {2, 16, 2}, {-1, 2, 4}}, K2[3][3] = {{7, -8, 1}, {-8, 16, -8}, {1, -8, 7}};
+  static const double M1[2][2] = {{2, 1}, {1, 2}}, K1[2][2] = {{1, -1}, {-1, 1}};
+  for (int c = 0; c < n_cells; ++c)
+    for (int a = 0; a <= k; ++a) for (int b = 0; b <= k; ++b) {
+      const size_t at = (size_t)(k * c + a) * nn + (k * c + b);
+      if (k == 2) { M[at] += h / 30.0 * M2[a][b]; K[at] += K2[a][b] / (3.0 * h); } else { M[at] += h / 6.0 * M1[a][b]; K[at] += K1[a][b] / h; }
+    }
+}
+
+}  // namespace
+
+// generalised eigenpairs K s = lam M s of the 1D FE_Q(k) matrices with the end nodes lo / hi removed when fix_lo / fix_hi:
+// S (nn x nn row-major, S^T M S = I on the free block, zero rows for removed nodes, zero columns behind the n_free modes), lam (inf behind n_free)
+void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::vector<double> &S, std::vector<double> &lam) {
+  std::vector<double> M, K; fe1d(k, n_cells, h, M, K);
+  const int nn = k * n_cells + 1, f0 = fix_lo ? 1 : 0, nf = nn - f0 - (fix_hi ? 1 : 0);
+  S.assign((size_t)nn * nn, 0.0); lam.assign(nn, std::numeric_limits<double>::infinity());
+  if (nf <= 0) return;
+  // Cholesky M_ff = L L^T, C = L^-1 K_ff L^-T, C = Q W Q^T, S_ff = L^-T Q
+  std::vector<double> Lc((size_t)nf * nf, 0.0), C((size_t)nf * nf);
+  for (int i = 0; i < nf; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = M[(size_t)(i + f0) * nn + (j + f0)];
+      for (int p = 0; p < j; ++p) s -= Lc[(size_t)i * nf + p] * Lc[(size_t)j * nf + p];
+      if (i == j) { if (!(s > 0)) throw Error("fdmu_eig_1d: mass matrix not positive definite"); Lc[(size_t)i * nf + i] = std::sqrt(s); }
+      else Lc[(size_t)i * nf + j] = s / Lc[(size_t)j * nf + j];
+    }
+  // X = L^-1 K_ff (forward substitution on columns), C = X L^-T = (L^-1 X^T)^T
+  std::vector<double> X((size_t)nf * nf);
+  for (int col = 0; col < nf; ++col)
+    for (int i = 0; i < nf; ++i) {
+      double s = K[(size_t)(i + f0) * nn + (col + f0)];
+      for (int p = 0; p < i; ++p) s -= Lc[(size_t)i * nf + p] * X[(size_t)p * nf + col];
+      X[(size_t)i * nf + col] = s / Lc[(size_t)i * nf + i];
+    }
+  for (int row = 0; row < nf; ++row)         // solve L y = X[row, :]^T  ->  C[:, row] = y
+    for (int i = 0; i < nf; ++i) {
+      double s = X[(size_t)row * nf + i];
+      for (int p = 0; p < i; ++p) s -= Lc[(size_t)i * nf + p] * C[(size_t)p * nf + row];
+      C[(size_t)i * nf + row] = s / Lc[(size_t)i * nf + i];
+    }
+  for (int i = 0; i < nf; ++i) for (int j = i + 1; j < nf; ++j) { const double a = 0.5 * (C[(size_t)i * nf + j] + C[(size_t)j * nf + i]); C[(size_t)i * nf + j] = C[(size_t)j * nf + i] = a; }
+  std::vector<double> Q, wv; jacobi_eig(nf, C, Q, wv);
+  for (int j = 0; j < nf; ++j) {             // back substitution L^T s = q_j
+    std::vector<double> sv(nf);
+    for (int i = nf - 1; i >= 0; --i) {
+      double s = Q[(size_t)i * nf + j];
+      for (int p = i + 1; p < nf; ++p) s -= Lc[(size_t)p * nf + i] * sv[p];
+      sv[i] = s / Lc[(size_t)i * nf + i];
+    }
+    for (int i = 0; i < nf; ++i) S[(size_t)(i + f0) * nn + j] = sv[i];
+    lam[j] = std::max(wv[j], 0.0);
+  }
+}
+
+namespace {
+// MFMA A-fragment order of the (nn x nn) matrix Tm (row-major; transposed access when `transpose`): [MT][KK][64], lane -> row 16 mt + (lane & 15), column 4 kk + (lane >> 4)
+template <class TC> void upload_fragments(DevBuf<double> &dst, const std::vector<double> &Tm, int nn, bool transpose) {
+  const int MT = (nn + 15) / 16, KK = (nn + 3) / 4;
+  std::vector<TC> f((size_t)MT * KK * 64, (TC)0);
+  for (int mt = 0; mt < MT; ++mt) for (int kk = 0; kk < KK; ++kk) for (int l = 0; l < 64; ++l) {
+    const int r = 16 * mt + (l & 15), cc = 4 * kk + (l >> 4);
+    if (r < nn && cc < nn) f[((size_t)mt * KK + kk) * 64 + l] = (TC)(transpose ? Tm[(size_t)cc * nn + r] : Tm[(size_t)r * nn + cc]);
+  }
+  const size_t bytes = f.size() * sizeof(TC);
+  dst.alloc((bytes + 7) / 8);
+  PORO_HIP(hipMemcpy(dst.p, f.data(), bytes, hipMemcpyHostToDevice));
+}
+}  // namespace
+
+void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single) {
+  D.n = nn;
+  if (single) { upload_fragments<float>(D.fwd, S, nn, true); upload_fragments<float>(D.bwd, S, nn, false); }
+  else { upload_fragments<double>(D.fwd, S, nn, true); upload_fragments<double>(D.bwd, S, nn, false); }
+  D.lam.upload(lam);
+}
+
+// z = blockdiag(A_cc)^-1 g.  g, z: node-interleaved vectors of the local grid nn[0] x nn[1] (x nn[2]); t1, t2: planar scratch of the same size.
+// z_lines != null (partitioned run): the last-direction pass works on whole global lines of this rank's column group, which the caller
+// gathers / scatters around it (see ctx.hip); then only the passes of the leading directions run here (stage 0: forward, 1: backward).
+template <class TC> static void fdmu_apply_t(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1v, void *t2v, int stage) {
+  TC *t1 = reinterpret_cast<TC *>(t1v), *t2 = reinterpret_cast<TC *>(t2v);
+  const int dim = F.dim; const int64_t nx = F.nn[0], ny = F.nn[1], nz = dim == 3 ? F.nn[2] : 1, nnode = nx * ny * nz;
+  auto pass = [&](int d, bool fwd, bool fused) {
+    FdmuPass P{};
+    P.nK = F.nn[d]; P.MT = (P.nK + 15) / 16; P.KK = (P.nK + 3) / 4;
+    P.SI = d == 0 ? 1 : d == 1 ? nx : nx * ny; P.n_lines = nnode / P.nK; P.comp_stride = nnode; P.ncomp = dim;
+    P.x_layout = d == 0 ? 1 : 0; P.ld_line = std::max(P.KK * 4, P.MT * 16) + 2;
+    P.fused = fused ? 1 : 0; P.n0 = (int)nx; P.col0 = 0; P.col_total = P.n_lines;
+    for (int c = 0; c < dim; ++c) {
+      const FdmuDir &D = F.dir[c][d];
+      P.T1[c] = (fwd || fused) ? (const void *)D.fwd.p : (const void *)D.bwd.p; P.T2[c] = D.bwd.p;
+      if (fused) {
+        P.lam_d[c] = D.lam.p; P.kd[c] = F.coef[c][d];
+        P.lam0[c] = F.dir[c][0].lam.p; P.k0[c] = F.coef[c][0];
+        P.lam1[c] = dim == 3 ? F.dir[c][1].lam.p : nullptr; P.k1[c] = dim == 3 ? F.coef[c][1] : 0.0;
+      }
+    }
+    return P;
+  };
+  const int last = dim - 1;
+  if (stage == 0 || stage == 2) {
+    FdmuPass P = pass(0, true, false); P.in_interleaved = 1;
+    launch_pass<TC, double, TC>(s, P, g, t1);                                    // x forward: g (interleaved) -> t1 (planar)
+    if (dim == 3) { P = pass(1, true, false); launch_pass<TC, TC, TC>(s, P, t1, t2); }   // y forward: t1 -> t2
+  }
+  if (stage == 2) {                                                               // single rank: last direction forward + scale + backward
+    FdmuPass P = pass(last, true, true);
+    if (dim == 3) launch_pass<TC, TC, TC>(s, P, t2, t1); else launch_pass<TC, TC, TC>(s, P, t1, t2);
+  }
+  if (stage == 1 || stage == 2) {
+    // 3D: data in t1 (single rank) or t2 (partitioned: scattered back into t2) ; 2D: in t2 (single) / t1 (partitioned)
+    if (dim == 3) {
+      FdmuPass P = pass(1, false, false);
+      if (stage == 2) { launch_pass<TC, TC, TC>(s, P, t1, t2); } else { launch_pass<TC, TC, TC>(s, P, t2, t1); }
+      P = pass(0, false, false); P.out_interleaved = 1;
+      if (stage == 2) launch_pass<TC, TC, double>(s, P, t2, z); else launch_pass<TC, TC, double>(s, P, t1, z);
+    } else {
+      FdmuPass P = pass(0, false, false); P.out_interleaved = 1;
+      if (stage == 2) launch_pass<TC, TC, double>(s, P, t2, z); else launch_pass<TC, TC, double>(s, P, t1, z);
+    }
+  }
+}
+void fdmu_apply(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1, void *t2, int stage) {
+  if (F.single) fdmu_apply_t<float>(s, F, g, z, t1, t2, stage); else fdmu_apply_t<double>(s, F, g, z, t1, t2, stage);
+}
+
+// the fused last-direction pass on a column-distributed array [component][global line point][C local columns] (partitioned runs)
+template <class TC> static void fdmu_lines_t(hipStream_t s, const FdmU &F, const FdmuDir *last_dir /*[dim]*/, int64_t C, int64_t col0, int64_t ncol_valid, void *in_v, void *out_v) {
+  const int dim = F.dim, last = dim - 1;
+  FdmuPass P{};
+  P.nK = last_dir[0].n; P.MT = (P.nK + 15) / 16; P.KK = (P.nK + 3) / 4;
+  P.SI = C; P.n_lines = C; P.comp_stride = (int64_t)P.nK * C; P.ncomp = dim; P.x_layout = 0; P.ld_line = 0;
+  P.fused = 1; P.n0 = F.nn[0]; P.col0 = col0; P.col_total = col0 + ncol_valid;   // padding columns hold zeros and stay zero
+  for (int c = 0; c < dim; ++c) {
+    P.T1[c] = last_dir[c].fwd.p; P.T2[c] = last_dir[c].bwd.p; P.lam_d[c] = last_dir[c].lam.p; P.kd[c] = F.coef[c][last];
+    P.lam0[c] = F.dir[c][0].lam.p; P.k0[c] = F.coef[c][0];
+    P.lam1[c] = dim == 3 ? F.dir[c][1].lam.p : nullptr; P.k1[c] = dim == 3 ? F.coef[c][1] : 0.0;
+  }
+  launch_pass<TC, TC, TC>(s, P, reinterpret_cast<const TC *>(in_v), reinterpret_cast<TC *>(out_v));
+}
+void fdmu_lines(hipStream_t s, const FdmU &F, const FdmuDir *last_dir, int64_t C, int64_t col0, int64_t ncol_valid, void *in, void *out) {
+  if (F.single) fdmu_lines_t<float>(s, F, last_dir, C, col0, ncol_valid, in, out); else fdmu_lines_t<double>(s, F, last_dir, C, col0, ncol_valid, in, out);
+}
+
+}  // namespace poro

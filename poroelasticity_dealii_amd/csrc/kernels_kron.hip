@@ -546,6 +546,12 @@ void check_q2_element_matrices() {
 
 bool kron_supported(int dim, int k_u) { return (dim == 2 || dim == 3) && (k_u == 1 || k_u == 2); }
 
+void kron_prepare_device() {
+  const int lds = (int)((size_t)NFLD * kTileNodes * sizeof(double));
+  PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q1, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+}
+
 int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1, const PcgScalars *pcg) {
   static bool checked = false;
   if (!checked) { check_q2_element_matrices(); checked = true; }
@@ -593,19 +599,15 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   for (int i = 0; i < 4; ++i) { k.cc_mz[i] = c[i] * sC * sC * sM[2]; k.cc_oz[i] = c[i] * sM[1] * sC * sC; k.cc_mx[i] = c[i] * sC * sM[0] * sC; }
   a.nodemask = m.nodemask; a.constrained = constrained ? 1 : 0; a.mask_anywhere = m.mask_anywhere;
   const size_t lds = (size_t)NFLD * kTileNodes * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   const int nblk = a.nblocks;
-  if (dot_partials && nblk > kMaxPartials / 2) throw Error("kron_apply: too many workgroups for the fused dot product");
-  a.dot_partials = dot_partials; a.pcg = pcg;
+  // one partial slot per workgroup: a box whose x-y extent needs more workgroups than slots runs without the fused x.y (negative return
+  // value = "no partials written"; the caller launches its separate dot kernel, exactly as for the assembled operator)
+  const bool fuse = dot_partials && nblk <= kMaxPartials / 2;
+  a.dot_partials = fuse ? dot_partials : nullptr; a.pcg = pcg;
   // ev0 / ev1 (optional): timestamps at the start / end of THIS dispatch, so the measured time is the kernel's own duration
   if (ku == 2) hipExtLaunchKernelGGL(k_kron3_q2, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
   else hipExtLaunchKernelGGL(k_kron3_q1, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
-  return nblk;
+  return (dot_partials && !fuse) ? -nblk : nblk;
 }
 
 // Dirichlet rows of y = A_c x after kron_apply (separate launch so that profiles attribute it separately); slot_base = first free

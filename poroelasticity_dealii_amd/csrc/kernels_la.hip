@@ -148,6 +148,9 @@ __global__ void k_jacobian(double *J, const double *M, const double *K, double a
 __global__ void k_reciprocal(double *y, const double *x, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] = 1.0 / x[i];
 }
+__global__ void k_pointwise_mul(double *y, const double *x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] *= x[i];
+}
 __global__ void k_csr_diag(int64_t n, const int64_t *pos, const double *val, double *diag) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) diag[i] = val[pos[i]];
 }
@@ -258,9 +261,9 @@ __global__ void k_scalars_sum(const PcgScalars *sc, const double *partials, int 
     if (threadIdx.x == 0) red[k] = v;
   }
 }
-__global__ void k_scalars_start(PcgScalars *sc, const double *red, double abs_tol, double rel_tol, int max_iter) {
+__global__ void k_scalars_start(PcgScalars *sc, const double *red, double abs_tol, double rel_tol, int max_iter, int stop_rule) {
   const double bb = red[0], gg = red[1], gz = red[2];
-  sc->tol = fmax(abs_tol, rel_tol * sqrt(bb));
+  sc->tol = fmax(abs_tol, rel_tol * sqrt(stop_rule == PORO_STOP_REDUCTION ? gg : bb));   // relative to ||b|| or to the warm start's residual
   sc->res0 = sc->res = sqrt(gg);
   sc->gg = gg; sc->gz = gz; sc->gh2[0] = gz; sc->gh2[1] = gz; sc->dh = 0; sc->alpha = 0; sc->beta = 0;
   sc->it = 0; sc->max_iter = max_iter;
@@ -424,6 +427,7 @@ void la_ilu_apply(hipStream_t s, const CsrDev &A, const double *lu, const SsorLe
   }
 }
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_reciprocal, grid_for(n), kBlock, 0, s, y, x, n); }
+void la_pointwise_mul(hipStream_t s, double *y, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_pointwise_mul, grid_for(n), kBlock, 0, s, y, x, n); }
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag) {
   hipLaunchKernelGGL(k_csr_diag, grid_for(A.n), kBlock, 0, s, A.n, A.diag_pos.p, val, diag);
 }
@@ -474,8 +478,8 @@ void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const doub
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red) {
   hipLaunchKernelGGL(k_scalars_sum, 1, kBlock, 0, s, (const PcgScalars *)nullptr, partials, n_sets, red);
 }
-void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red, double abs_tol, double rel_tol, int max_iter) {
-  hipLaunchKernelGGL(k_scalars_start, 1, 1, 0, s, sc, red, abs_tol, rel_tol, max_iter);
+void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red, double abs_tol, double rel_tol, int max_iter, int stop_rule) {
+  hipLaunchKernelGGL(k_scalars_start, 1, 1, 0, s, sc, red, abs_tol, rel_tol, max_iter, stop_rule);
 }
 void pcg_update_g_fused(hipStream_t s, PcgScalars *sc, int parity, double *g, const double *h, const DiagVec &dv, int prec, int64_t n, int64_t n_owned,
                         const double *partials_dh, const double *red, double *partials_out) {

@@ -42,6 +42,7 @@ struct RunControls {
   double p_init = 10e6, time_step = 60; int n_steps = 1;
   double fss_tol = 1e-8, pressure_tol = 1e-8; int max_fss_iterations = 50, max_pressure_iterations = 50;
   double abs_tol_u = 1e-12, rel_tol_u = 0.0; int max_iter = 1000;   // PoroElasticDisplacementSolver.h:298-299
+  int stop_rule_u = PORO_STOP_RHS;                                  // PORO_STOP_REDUCTION: rel_tol_u is taken against the residual of the warm start (every step of a transient solves)
   int preconditioner = PORO_PREC_JACOBI;                            // displacement solve; PORO_PREC_SSOR = the reference's PreconditionSSOR (CSR operator, one rank) for all three systems
   bool coupled_fss = false;                                         // true = restore the get_volumetric_strain() call the reference commented out (:399): eps_v follows the new
                                                                     // displacement inside the fixed-stress loop, which then really iterates (SURVEY 8f-4 "corrected physics", first half)
@@ -59,7 +60,7 @@ using poro_host::DeviceVector;
 template <int dim> class PoroElasticDisplacementSolver {
  public:
   DeviceVector solution;                                   // PoroElasticDisplacementSolver.h:47
-  poro_solver_opts control{1e-12, 0.0, 1000, PORO_PREC_JACOBI, 1.2};   // :298-299, omega :303 (Jacobi is the fast default; PORO_PREC_SSOR = the reference's)
+  poro_solver_opts control{1e-12, 0.0, 1000, PORO_PREC_JACOBI, 1.2, PORO_STOP_RHS, 0};   // :298-299, omega :303 (Jacobi is the fast default; PORO_PREC_SSOR = the reference's)
   poro_solve_info  last{};
   explicit PoroElasticDisplacementSolver(poro_ctx *c) : ctx(c) { solution.ctx = c; solution.id = PORO_VEC_U; }
   void setup_dofs() { rebuild_system_matrix = true; }      // :106-153 (pattern / constraints are built by poro_ctx_create)
@@ -81,7 +82,7 @@ template <int dim> class PoroElasticDisplacementSolver {
 template <int dim> class PoroElasticPressureSolver {
  public:
   DeviceVector solution, solution_update, old_solution, residual;   // PoroElasticPressureSolver.h:38-40
-  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI, 1.0};       // :175, omega :178
+  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI, 1.0, PORO_STOP_RHS, 0};       // :175, omega :178
   poro_solve_info  last{};
   explicit PoroElasticPressureSolver(poro_ctx *c) : ctx(c) {
     solution.ctx = solution_update.ctx = old_solution.ctx = residual.ctx = c;
@@ -112,7 +113,7 @@ template <int dim> class PoroElasticPressureSolver {
 namespace projection {
 template <int dim> class StrainProjector {
  public:
-  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI, 1.0};       // StrainProjector.h:209, omega :212
+  poro_solver_opts control{0.0, 1e-8, 1000, PORO_PREC_JACOBI, 1.0, PORO_STOP_RHS, 0};       // StrainProjector.h:209, omega :212
   poro_solve_info  last{};
   StrainProjector() {}
   void set_solvers(poro_ctx *c) { ctx = c; }               // :73-79
@@ -244,7 +245,7 @@ template <int dim> class PoroElasticProblem {
 
   // trace rows: [step, fss_iteration, pressure_iterations, inner pressure error, |p|_inf, error after displacement, u CG its, p CG its]
   void initialize(const RunControls &rc) {
-    displacement_solver.control.abs_tol = rc.abs_tol_u; displacement_solver.control.rel_tol = rc.rel_tol_u;
+    displacement_solver.control.abs_tol = rc.abs_tol_u; displacement_solver.control.rel_tol = rc.rel_tol_u; displacement_solver.control.stop_rule = rc.stop_rule_u;
     displacement_solver.control.max_iter = pressure_solver.control.max_iter = strain_projector.control.max_iter = rc.max_iter;
     displacement_solver.control.preconditioner = rc.preconditioner;
     pressure_solver.control.preconditioner = strain_projector.control.preconditioner =

@@ -30,6 +30,26 @@ def test_single_rank_line():
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "hbm"
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"]
+    assert len(d["cg_iterations_u"]) == 1 and min(d["cg_iterations_u"][0]) > 0     # every timed step does a live displacement solve
+    assert "reduction" in d["config"]["stopping_rule_u"].lower() or "g_0" in d["config"]["stopping_rule_u"]
+    tts = d["time_to_solution"]["block_fdm"]
+    assert "error" not in tts, tts
+    assert max(tts["cg_iterations_u"][0]) <= 40 and tts["applications_precondition_u"] > 0
+
+
+def test_live_steps_do_not_depend_on_the_window():
+    """the warm-started transient keeps solving: later steps take about as many CG iterations as the first (the r1 bench measured empty steps)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "4", "--cells", "8", "--no-cpu-baseline", "--no-variants"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    its = [t[0] for t in _line(r.stdout)["cg_iterations_u"]]
+    assert min(its) > 0 and max(its) <= 2 * min(its), its
+
+
+def test_dead_steps_fail_the_run():
+    """with the ||b||-relative rule the transient dies after a few steps on this tiny mesh: bench.py must refuse to report such a window"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "40", "--cells", "4", "--stop", "rhs", "--rel-tol", "1e-6", "--no-cpu-baseline", "--no-variants"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stdout[-500:], r.stderr[-500:])
 
 
 def test_two_rank_rehearsal():
@@ -38,6 +58,7 @@ def test_two_rank_rehearsal():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
-    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert "8x8x16" in d["config"]["workload"]                     # weak scaling: the box grows along the partitioned direction
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert "8x8x8" in d["config"]["workload"]                      # strong scaling: the BASELINE mesh itself is cut into slabs
+    assert d["weak_scaling_line"]["cells"] == "8x8x16" and d["weak_scaling_line"]["value"] > 0     # the box grown along the partitioned direction
     assert d["work_per_step"]["cg_p"] <= 2 * d["work_per_step"]["residual_p"]     # distributed fast diagonalisation in use
