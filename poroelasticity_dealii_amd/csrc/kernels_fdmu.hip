@@ -22,6 +22,7 @@
 #include "common.hpp"
 #include <cmath>
 #include <limits>
+#include <type_traits>
 
 namespace poro {
 namespace {
@@ -48,6 +49,7 @@ struct FdmuPass {
   int ld_line;          // x_layout: LDS stride between lines
   // fused scaling (last direction): D(m, line) /= kd * lam_d[m] + k0 * lam0[i] + k1 * lam1[j], (i, j) = grid position of the line
   int fused; int n0; int64_t col0, col_total; double kd[3], k0[3], k1[3];
+  int reg_form;         // 1: register-panel kernel (T1 / T2 point at the chunked fragment order of k_fdmu_reg)
   const void *T1[3], *T2[3];             // per component: transform matrices in MFMA fragment order [MT][KK][64]
   const double *lam_d[3], *lam0[3], *lam1[3];
 };
@@ -178,8 +180,152 @@ k_fdmu_pass(FdmuPass P, const TIn *__restrict__ in, TOut *__restrict__ out) {
   }
 }
 
+// ---- register-panel form (lines of <= 160 points, fp64): no LDS traffic for the data at all ------------------------------------------
+// A wave owns 16 grid lines.  Their points go straight from global memory into MFMA B-fragment registers (lane (j, kq) holds points
+// k = 4 kk + kq of line j for every k-step kk: <= 40 doubles), the transform matrix streams through LDS in chunks of 4 k-steps shared by
+// the 4 waves of the workgroup (double buffered, one barrier per chunk, 16-byte LDS reads feeding two MFMAs each), and the D fragments are
+// stored from the accumulators.  The D layout of v_mfma_f64_16x16x4_f64 (register q of a lane = row kq + 4 q of the tile, column j) IS the
+// B layout of the next GEMM (k-step 4 mt + q of the same lane), so the fused last-direction pass chains its two GEMMs without moving data.
+template <int NCH> struct RegGeom { static constexpr int MTP = (NCH + 1) / 2, MT = 2 * MTP, KKP = 4 * NCH, CHUNK = 4 * MTP * 128; };
+
+// MODE 0: data as the B operand (y / z passes: 16 consecutive lines per tile are contiguous in memory, loads and stores run in 128-byte pieces);
+// MODE 1: the same with the scaling and the second GEMM fused (last direction); MODE 2: data as the A operand (x passes: the SAME registers,
+// only the operand order of the MFMA changes, and D comes out transposed - lane = point of the line - so the stores are contiguous along x).
+// The data fragments of chunk ch + kAhead are requested while chunk ch multiplies (the loads stay behind the chunk's barrier).
+template <int NCH, int MODE>
+__global__ void __launch_bounds__(kThreads, MODE == 0 ? 1 : 2)   // (measured per mode: the register cap of two waves per SIMD pays for the fused and the x passes only)
+k_fdmu_reg(FdmuPass P, const double *__restrict__ in, double *__restrict__ out) {
+  typedef RegGeom<NCH> Gm;
+  constexpr int kAhead = NCH < 3 ? NCH : 3;
+  __shared__ double LT[2][Gm::CHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = blockIdx.y, j = lane & 15, kq = lane >> 4;
+  const int64_t n_tile = (int64_t)blockIdx.x * 64 + w * 16;
+  const int64_t n = n_tile + j;
+  const bool valid = n < P.n_lines;
+  // element (k, line n) of the input / output arrays at base + k * stride.  Loads are never predicated: lines behind the end re-read the
+  // last line and points behind the line's end re-read its last point (finite values that only meet zero columns of T or are never stored)
+  const int64_t nc = valid ? n : P.n_lines - 1;
+  const int64_t lb = P.SI == 1 ? nc * P.nK : line_base(P, nc);
+  const int64_t in_stride = P.in_interleaved ? P.SI * P.ncomp : P.SI, out_stride = P.out_interleaved ? P.SI * P.ncomp : P.SI;
+  const double *in_lane = in + (P.in_interleaved ? lb * P.ncomp + c : (int64_t)c * P.comp_stride + lb);
+  const int k_last = P.nK - 1;
+
+  double b[Gm::KKP];
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int kk = 4 * ch + u; const int k = min(4 * kk + kq, k_last); b[kk] = in_lane[(int64_t)k * in_stride]; }
+  };
+#pragma unroll
+  for (int ch = 0; ch < kAhead; ++ch) load_chunk(ch);
+
+  v4d acc[Gm::MT];
+  // D = T * B (or B^T * T^T for MODE 2) with T in chunked fragment order [chunk][k-step in chunk][tile pair][lane][2]
+  auto gemm = [&](const double *__restrict__ Tg, double (&bb)[Gm::KKP], const bool stream_b, const bool swapped) {
+#pragma unroll
+    for (int t = 0; t < Gm::MT; ++t) acc[t] = v4d{0, 0, 0, 0};
+    constexpr int PER = Gm::CHUNK / 2 / kThreads;   // double2 per thread and chunk = MTP
+    double2 stage[PER];
+    const double2 *src = reinterpret_cast<const double2 *>(Tg);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) reinterpret_cast<double2 *>(LT[0])[tid + i * kThreads] = src[tid + i * kThreads];
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (ch + 1 < NCH) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) stage[i] = src[(int64_t)(ch + 1) * (Gm::CHUNK / 2) + tid + i * kThreads];
+      }
+      if (stream_b && ch + kAhead < NCH) load_chunk(ch + kAhead);
+      const double2 *La = reinterpret_cast<const double2 *>(LT[ch & 1]) + lane;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = 4 * ch + u;
+        if (ch + 1 < NCH || u == 0 || kk < P.KK) {         // wave-uniform, last chunk only: k-steps behind the line length are skipped
+#pragma unroll
+          for (int p = 0; p < Gm::MTP; ++p) {
+            const double2 a = La[(u * Gm::MTP + p) * 64];
+            if (swapped) {
+              acc[2 * p] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[kk], a.x, acc[2 * p], 0, 0, 0);
+              acc[2 * p + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[kk], a.y, acc[2 * p + 1], 0, 0, 0);
+            } else {
+              acc[2 * p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bb[kk], acc[2 * p], 0, 0, 0);
+              acc[2 * p + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bb[kk], acc[2 * p + 1], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (ch + 1 < NCH) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) reinterpret_cast<double2 *>(LT[(ch + 1) & 1])[tid + i * kThreads] = stage[i];
+      }
+      __syncthreads();
+    }
+  };
+
+  gemm(reinterpret_cast<const double *>(P.T1[c]), b, true, MODE == 2);
+  if constexpr (MODE == 1) {
+    double base = 0;
+    const int64_t col = min(P.col0 + nc, P.col_total - 1);     // (lines behind the end: any valid column, the result is never stored)
+    if (P.lam1[c]) { const int64_t jj = col / P.n0; base = P.k0[c] * P.lam0[c][col - jj * P.n0] + P.k1[c] * P.lam1[c][jj]; }
+    else if (P.lam0[c]) base = P.k0[c] * P.lam0[c][col];
+    double b2[Gm::KKP];
+    const double *lam_lane = P.lam_d[c]; const double kdc = P.kd[c];
+#pragma unroll
+    for (int mt = 0; mt < Gm::MT; ++mt) {     // D register (mt, q) of this lane = B operand of k-step 4 mt + q
+      double den[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) den[q] = fma(kdc, lam_lane[min(16 * mt + kq + 4 * q, k_last)], base);   // removed modes carry lam = inf -> factor 0
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // reciprocal by v_rcp_f64 + one Newton step (full division sequences would cost a quarter of the GEMM); den = inf gives exactly 0
+        double r = __builtin_amdgcn_rcp(den[q]);
+        r = den[q] < 1e300 ? fma(r, fma(-den[q], r, 1.0), r) : 0.0;
+        b2[4 * mt + q] = acc[mt][q] * r;       // rows behind the line's end are exact zeros of T
+      }
+      __builtin_amdgcn_sched_barrier(0);       // keep the eigenvalue loads of the next tile from piling up in registers
+    }
+    gemm(reinterpret_cast<const double *>(P.T2[c]), b2, false, false);
+  }
+  if constexpr (MODE == 2) {
+    // transposed D: lane j = point 16 t + j of the line, register q = line kq + 4 q of the tile (x direction: SI == 1)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t nl = n_tile + kq + 4 * q;
+      if (nl >= P.n_lines) continue;
+      const int64_t ob = P.out_interleaved ? nl * P.nK * P.ncomp + c : (int64_t)c * P.comp_stride + nl * P.nK;
+#pragma unroll
+      for (int t = 0; t < Gm::MT; ++t) { const int m = 16 * t + j; if (m < P.nK) out[ob + (int64_t)m * out_stride] = acc[t][q]; }
+    }
+  } else if (valid) {
+    const int64_t out_base = P.out_interleaved ? lb * P.ncomp + c : (int64_t)c * P.comp_stride + lb;
+#pragma unroll
+    for (int t = 0; t < Gm::MT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int m = 16 * t + kq + 4 * q; if (m < P.nK) out[out_base + (int64_t)m * out_stride] = acc[t][q]; }
+  }
+}
+
+inline int reg_nch(int nK) { const int need = (nK + 15) / 16; for (int v : {1, 2, 3, 5, 7, 10}) if (need <= v) return v; return 0; }
+
+void launch_reg(hipStream_t s, const FdmuPass &P, const double *in, double *out) {
+  const dim3 grid((unsigned)((P.n_lines + 63) / 64), (unsigned)P.ncomp);
+  const int mode = P.fused ? 1 : (P.SI == 1 && !std::getenv("PORO_FDMU_NO_SWAP")) ? 2 : 0;
+  switch (reg_nch(P.nK) * 4 + mode) {
+#define PORO_REG_CASE(N) case 4 * N: hipLaunchKernelGGL((k_fdmu_reg<N, 0>), grid, dim3(kThreads), 0, s, P, in, out); break; \
+                         case 4 * N + 1: hipLaunchKernelGGL((k_fdmu_reg<N, 1>), grid, dim3(kThreads), 0, s, P, in, out); break; \
+                         case 4 * N + 2: hipLaunchKernelGGL((k_fdmu_reg<N, 2>), grid, dim3(kThreads), 0, s, P, in, out); break;
+    PORO_REG_CASE(1) PORO_REG_CASE(2) PORO_REG_CASE(3) PORO_REG_CASE(5) PORO_REG_CASE(7) PORO_REG_CASE(10)
+#undef PORO_REG_CASE
+    default: throw Error("launch_reg: line too long");
+  }
+}
+
 template <class TC, class TIn, class TOut>
 void launch_pass(hipStream_t s, const FdmuPass &P, const TIn *in, TOut *out) {
+  if constexpr (std::is_same<TC, double>::value && std::is_same<TIn, double>::value && std::is_same<TOut, double>::value) {
+    if (P.reg_form) { launch_reg(s, P, in, out); return; }
+  }
   const int rows = std::max(P.KK * 4, P.MT * 16);
   const size_t lds = sizeof(TC) * (size_t)(P.x_layout ? kNT * P.ld_line : rows * kLdK);
   const dim3 grid((unsigned)((P.n_lines + kNT - 1) / kNT), (unsigned)P.ncomp);
@@ -304,8 +450,20 @@ template <class TC> void upload_fragments(DevBuf<double> &dst, const std::vector
 }
 }  // namespace
 
+// chunked order of k_fdmu_reg: [chunk][k-step u][tile pair p][lane][2]; lane -> row 16 (2p + e) + (lane & 15), column 4 (4 chunk + u) + (lane >> 4)
+static void upload_chunked(DevBuf<double> &dst, const std::vector<double> &Tm, int nn, bool transpose) {
+  const int nch = reg_nch(nn), mtp = (nch + 1) / 2;
+  std::vector<double> f((size_t)nch * 4 * mtp * 128, 0.0);
+  for (int ch = 0; ch < nch; ++ch) for (int u = 0; u < 4; ++u) for (int p = 0; p < mtp; ++p) for (int l = 0; l < 64; ++l) for (int e = 0; e < 2; ++e) {
+    const int r = 16 * (2 * p + e) + (l & 15), cc = 4 * (4 * ch + u) + (l >> 4);
+    if (r < nn && cc < nn) f[(((size_t)(ch * 4 + u) * mtp + p) * 64 + l) * 2 + e] = transpose ? Tm[(size_t)cc * nn + r] : Tm[(size_t)r * nn + cc];
+  }
+  dst.upload(f);
+}
+
 void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single) {
-  D.n = nn;
+  D.n = nn; D.reg_form = !single && reg_nch(nn) > 0 && !std::getenv("PORO_FDMU_LDS_FORM");
+  if (D.reg_form) { upload_chunked(D.fwd, S, nn, true); upload_chunked(D.bwd, S, nn, false); D.lam.upload(lam); return; }
   if (single) { upload_fragments<float>(D.fwd, S, nn, true); upload_fragments<float>(D.bwd, S, nn, false); }
   else { upload_fragments<double>(D.fwd, S, nn, true); upload_fragments<double>(D.bwd, S, nn, false); }
   D.lam.upload(lam);
@@ -322,7 +480,7 @@ template <class TC> static void fdmu_apply_t(hipStream_t s, const FdmU &F, const
     P.nK = F.nn[d]; P.MT = (P.nK + 15) / 16; P.KK = (P.nK + 3) / 4;
     P.SI = d == 0 ? 1 : d == 1 ? nx : nx * ny; P.n_lines = nnode / P.nK; P.comp_stride = nnode; P.ncomp = dim;
     P.x_layout = d == 0 ? 1 : 0; P.ld_line = std::max(P.KK * 4, P.MT * 16) + 2;
-    P.fused = fused ? 1 : 0; P.n0 = (int)nx; P.col0 = 0; P.col_total = P.n_lines;
+    P.fused = fused ? 1 : 0; P.n0 = (int)nx; P.col0 = 0; P.col_total = P.n_lines; P.reg_form = F.dir[0][d].reg_form ? 1 : 0;
     for (int c = 0; c < dim; ++c) {
       const FdmuDir &D = F.dir[c][d];
       P.T1[c] = (fwd || fused) ? (const void *)D.fwd.p : (const void *)D.bwd.p; P.T2[c] = D.bwd.p;
@@ -367,7 +525,7 @@ template <class TC> static void fdmu_lines_t(hipStream_t s, const FdmU &F, const
   FdmuPass P{};
   P.nK = last_dir[0].n; P.MT = (P.nK + 15) / 16; P.KK = (P.nK + 3) / 4;
   P.SI = C; P.n_lines = C; P.comp_stride = (int64_t)P.nK * C; P.ncomp = dim; P.x_layout = 0; P.ld_line = 0;
-  P.fused = 1; P.n0 = F.nn[0]; P.col0 = col0; P.col_total = col0 + ncol_valid;   // padding columns hold zeros and stay zero
+  P.fused = 1; P.n0 = F.nn[0]; P.col0 = col0; P.col_total = col0 + ncol_valid; P.reg_form = last_dir[0].reg_form ? 1 : 0;   // padding columns hold zeros and stay zero
   for (int c = 0; c < dim; ++c) {
     P.T1[c] = last_dir[c].fwd.p; P.T2[c] = last_dir[c].bwd.p; P.lam_d[c] = last_dir[c].lam.p; P.kd[c] = F.coef[c][last];
     P.lam0[c] = F.dir[c][0].lam.p; P.k0[c] = F.coef[c][0];
