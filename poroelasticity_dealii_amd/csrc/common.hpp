@@ -75,7 +75,10 @@ struct FdmDist {
 // S (bwd) in MFMA fragment order and the eigenvalues (inf marks removed modes); coef[c][d] = lambda + 2G (d == c) | G
 struct FdmuDir { int n = 0; bool reg_form = false; DevBuf<double> fwd, bwd, lam; };
 struct FdmU { int dim = 0; int nn[3] = {1, 1, 1}; double coef[3][3] = {}; FdmuDir dir[3][3]; FdmuDir last_global[3]; bool built = false, single = false;
-              int fix[3][3][2] = {}; };
+              int fix[3][3][2] = {};
+              // slab-partitioned form: node planes of the last direction are gathered per column group by an all-to-all (as FdmDist for the Q1 systems)
+              bool dist = false; int n_ranks = 1, rank = 0; std::vector<int> layers, off /* first global node plane of every rank */; int ng = 0; int64_t ncol_total = 0, C = 0;
+              int max_own = 0, max_nl = 0; DevBuf<double> sendbuf, recvbuf, tz1, tz2; };
 // dependency levels of the lower / upper triangle in natural row order (rows of one level can be swept concurrently)
 struct SsorLevels { DevBuf<int32_t> fwd_rows, bwd_rows; std::vector<int64_t> fwd_off, bwd_off; bool built = false; };
 struct CsrDev {
@@ -232,6 +235,8 @@ void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::ve
 void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single);
 // stage 2: the whole application (single rank); 0 / 1: the passes of the leading directions before / after the caller's distributed last direction
 void fdmu_apply(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1, void *t2, int stage);
+void fdmu_window(hipStream_t s, double *dst, const double *src, bool to_block, int ncomp, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid,
+                 int64_t grid_stride, int64_t grid_planes, int64_t grid_col0, int64_t grid_plane0);
 void fdmu_lines(hipStream_t s, const FdmU &F, const FdmuDir *last_dir, int64_t C, int64_t col0, int64_t ncol_valid, void *in, void *out);
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
 int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,

@@ -453,7 +453,7 @@ void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk) {
     }
     PORO_NCCL(g_rccl.GroupEnd());
   } else if (cm.sr) {
-    FdmDist &F = c->fdm_dist; F.hsend.resize(blk); F.hrecv.resize(blk);
+    FdmDist &F = c->fdm_dist; if ((int64_t)F.hsend.size() < blk) { F.hsend.resize(blk); F.hrecv.resize(blk); }
     for (int step = 0; step < N; ++step) {                       // pairwise schedule: at step s rank r meets (s - r) mod N, which meets r
       const int q = ((step - r) % N + N) % N;
       if (q == r) continue;
@@ -505,60 +505,133 @@ void fdm_precondition_p(poro_ctx *c, double a, const double k[3], const double *
 void analyse_fdm_u(poro_ctx *c) {
   if (c->fdm_u_state != 0) return;
   c->fdm_u_state = -1;
-  if (!c->box.enabled || !c->interleaved_u) { c->fdm_u_why = "needs a uniform box with node-interleaved displacement dofs"; return; }
-  if (c->comm.multi()) { c->fdm_u_why = "PORO_PREC_FDM for the displacement system is implemented for one rank"; return; }
-  const int dim = c->dim; const int64_t nn[3] = {c->box.nn[0], c->box.nn[1], dim == 3 ? c->box.nn[2] : 1};
-  for (int d = 0; d < dim; ++d) if (nn[d] > 320) { c->fdm_u_why = "more than 320 nodes per grid line"; return; }
-  const std::vector<uint8_t> &nm = c->h_node_mask;
-  auto node = [&](int64_t i, int64_t j, int64_t k) { return (k * nn[1] + j) * nn[0] + i; };
+  const bool multi = c->comm.multi();
+  if (multi && !(c->comm.nccl_comm || (c->comm.ar && c->comm.sr))) { c->fdm_u_state = 0; c->fdm_u_why = "partitioned context without a communicator yet"; return; }
+  const int dim = c->dim, last = dim - 1; const int64_t nn[3] = {c->box.nn[0], c->box.nn[1], dim == 3 ? c->box.nn[2] : 1};
+  std::string why;
   FdmU &F = c->fdm_u;
-  for (int comp = 0; comp < dim; ++comp) {
-    bool any = false;
-    for (int d = 0; d < dim; ++d) for (int side = 0; side < 2; ++side) {
-      bool all = true;
-      const int64_t fixed = side ? nn[d] - 1 : 0;
-      const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
-      for (int64_t a = 0; a < nn[d1] && all; ++a) for (int64_t b = 0; b < nn[d2]; ++b) {
-        int64_t ix[3]; ix[d] = fixed; ix[d1] = a; ix[d2] = b;
-        if (!(nm[node(ix[0], ix[1], ix[2])] >> comp & 1)) { all = false; break; }
+  if (!c->box.enabled || !c->interleaved_u) why = "needs a uniform box with node-interleaved displacement dofs";
+  else {
+    for (int d = 0; d < dim; ++d) if (nn[d] > 320) why = "more than 320 nodes per grid line";
+  }
+  if (why.empty()) {
+    const std::vector<uint8_t> &nm = c->h_node_mask;
+    auto node = [&](int64_t i, int64_t j, int64_t k) { return (k * nn[1] + j) * nn[0] + i; };
+    // a face of the partitioned direction is a physical boundary only at the first / last rank
+    auto physical = [&](int d, int side) { return !(multi && d == last && (side == 0 ? c->comm.part.has_lower : c->comm.part.has_upper)); };
+    for (int comp = 0; comp < dim && why.empty(); ++comp) {
+      for (int d = 0; d < dim; ++d) for (int side = 0; side < 2; ++side) {
+        bool all = physical(d, side);
+        const int64_t fixed = side ? nn[d] - 1 : 0;
+        const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+        for (int64_t a = 0; a < nn[d1] && all; ++a) for (int64_t b = 0; b < nn[d2]; ++b) {
+          int64_t ix[3]; ix[d] = fixed; ix[d1] = a; ix[d2] = b;
+          if (!(nm[node(ix[0], ix[1], ix[2])] >> comp & 1)) { all = false; break; }
+        }
+        F.fix[comp][d][side] = all ? 1 : 0;
       }
-      F.fix[comp][d][side] = all ? 1 : 0; any = any || all;
-    }
-    if (!any) { c->fdm_u_why = "a displacement component without a constrained face (singular block)"; return; }
-    for (int64_t k = 0; k < nn[2]; ++k) for (int64_t j = 0; j < nn[1]; ++j) for (int64_t i = 0; i < nn[0]; ++i) {
-      const int64_t ix[3] = {i, j, k}; bool on = false;
-      for (int d = 0; d < dim; ++d) on = on || (ix[d] == 0 && F.fix[comp][d][0]) || (ix[d] == nn[d] - 1 && F.fix[comp][d][1]);
-      if (on != (bool)(nm[node(i, j, k)] >> comp & 1)) { c->fdm_u_why = "Dirichlet dofs are not a union of whole faces per component"; return; }
+      for (int64_t k = 0; k < nn[2] && why.empty(); ++k) for (int64_t j = 0; j < nn[1] && why.empty(); ++j) for (int64_t i = 0; i < nn[0]; ++i) {
+        const int64_t ix[3] = {i, j, k}; bool on = false;
+        for (int d = 0; d < dim; ++d) on = on || (ix[d] == 0 && F.fix[comp][d][0]) || (ix[d] == nn[d] - 1 && F.fix[comp][d][1]);
+        if (on != (bool)(nm[node(i, j, k)] >> comp & 1)) { why = "Dirichlet dofs are not a union of whole faces per component"; break; }
+      }
     }
   }
-  c->fdm_u_state = 1;
+  // ranks agree on the verdict and on the face flags (the end faces of the partitioned direction live on the first / last rank only)
+  if (multi) {
+    double h[kScalarSlots] = {0}; int m = 0;
+    for (int comp = 0; comp < 3; ++comp) for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) h[m++] = (comp < dim && d < dim) ? F.fix[comp][d][side] : 0;
+    h[m++] = why.empty() ? 0.0 : 1.0;
+    PORO_HIP(hipMemcpyAsync(c->red.p, h, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    allreduce_sum(c, c->red.p, m);
+    PORO_HIP(hipMemcpyAsync(h, c->red.p, m * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+    m = 0;
+    for (int comp = 0; comp < 3; ++comp) for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) { if (comp < dim && d < dim) F.fix[comp][d][side] = h[m] > 0.5 ? 1 : 0; ++m; }
+    if (h[m] > 0.5 && why.empty()) why = "another rank's Dirichlet dofs are not face-separable";
+  }
+  if (why.empty()) for (int comp = 0; comp < dim; ++comp) {
+    bool any = false;
+    for (int d = 0; d < dim; ++d) any = any || F.fix[comp][d][0] || F.fix[comp][d][1];
+    if (!any) why = "a displacement component without a constrained face (singular block)";
+  }
+  c->fdm_u_why = why;
+  c->fdm_u_state = why.empty() ? 1 : -1;
 }
 void build_fdm_u(poro_ctx *c) {
   FdmU &F = c->fdm_u;
   if (F.built) return;
   analyse_fdm_u(c);
   if (c->fdm_u_state != 1) throw Error("PORO_PREC_FDM (displacement): " + c->fdm_u_why);
-  const int dim = c->dim;
-  F.dim = dim; F.single = std::getenv("PORO_FDMU_SINGLE") != nullptr;   // fp32 transforms (experimental switch)
+  const int dim = c->dim, last = dim - 1, ku = c->k_u;
+  const bool multi = c->comm.multi();
+  F.dim = dim; F.single = !multi && std::getenv("PORO_FDMU_SINGLE") != nullptr;   // fp32 transforms (experimental switch, one rank)
   for (int d = 0; d < 3; ++d) F.nn[d] = d < dim ? c->box.nn[d] : 1;
   const double l2g = c->mat.lame_lambda + 2 * c->mat.shear_G, G = c->mat.shear_G;
   for (int comp = 0; comp < dim; ++comp) for (int d = 0; d < dim; ++d) F.coef[comp][d] = d == comp ? l2g : G;
+  int n_cells_last = c->box.n[last];
+  if (multi) {
+    // every rank learns all slab thicknesses through the existing all-reduce
+    const int N = std::max(1, c->comm.part.n_ranks), r = c->comm.part.rank;
+    F.dist = true; F.n_ranks = N; F.rank = r;
+    std::vector<double> lay(N, 0.0); lay[r] = c->box.n[last];
+    DevBuf<double> tmp; tmp.upload(lay);
+    for (int base = 0; base < N; base += kScalarSlots) {
+      const int m = std::min(kScalarSlots, N - base);
+      PORO_HIP(hipMemcpyAsync(c->red.p, tmp.p + base, m * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      allreduce_sum(c, c->red.p, m);
+      PORO_HIP(hipMemcpyAsync(lay.data() + base, c->red.p, m * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+    }
+    F.layers.resize(N); F.off.resize(N); int acc = 0;
+    for (int q = 0; q < N; ++q) { F.layers[q] = (int)std::lround(lay[q]); F.off[q] = ku * acc; acc += F.layers[q]; }
+    n_cells_last = acc; F.ng = ku * acc + 1;
+    if (F.ng > 320) throw Error("PORO_PREC_FDM (displacement): more than 320 nodes per global grid line");
+    F.ncol_total = 1; for (int d = 0; d < last; ++d) F.ncol_total *= F.nn[d];
+    F.C = (F.ncol_total + N - 1) / N;
+    F.max_own = 0; F.max_nl = 0;
+    for (int q = 0; q < N; ++q) { F.max_own = std::max(F.max_own, ku * F.layers[q] + (q == N - 1 ? 1 : 0)); F.max_nl = std::max(F.max_nl, ku * F.layers[q] + 1); }
+    const size_t blk = (size_t)dim * std::max(F.max_own, F.max_nl) * F.C;
+    F.sendbuf.alloc(blk * N); F.recvbuf.alloc(blk * N); F.tz1.alloc((size_t)dim * F.ng * F.C); F.tz2.alloc((size_t)dim * F.ng * F.C);
+  }
   // eigenpairs per (direction, end conditions); components with the same end conditions share the host work
   for (int d = 0; d < dim; ++d) {
     std::vector<double> S[4], lam[4]; bool have[4] = {false, false, false, false};
+    const bool global_dir = multi && d == last;
+    const int ncell = global_dir ? n_cells_last : c->box.n[d], nnode = ku * ncell + 1;
     for (int comp = 0; comp < dim; ++comp) {
       const int key = F.fix[comp][d][0] * 2 + F.fix[comp][d][1];
-      if (!have[key]) { fdmu_eig_1d(c->k_u, c->box.n[d], c->box.h[d], F.fix[comp][d][0], F.fix[comp][d][1], S[key], lam[key]); have[key] = true; }
-      fdmu_upload_dir(F.dir[comp][d], S[key], lam[key], F.nn[d], F.single);
+      if (!have[key]) { fdmu_eig_1d(ku, ncell, c->box.h[d], F.fix[comp][d][0], F.fix[comp][d][1], S[key], lam[key]); have[key] = true; }
+      if (global_dir) fdmu_upload_dir(F.last_global[comp], S[key], lam[key], nnode, false);
+      else fdmu_upload_dir(F.dir[comp][d], S[key], lam[key], nnode, F.single);
     }
   }
   c->fdmu_t1.alloc(c->n_u); c->fdmu_t2.alloc(c->n_u);
   if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
   F.built = true;
 }
+void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk);
 void fdm_precondition_u(poro_ctx *c, const double *g, double *z) {
   Timed tm(c, "precondition_u_fdm");
-  fdmu_apply(c->stream, c->fdm_u, g, z, c->fdmu_t1.p, c->fdmu_t2.p, 2);
+  hipStream_t s = c->stream; FdmU &F = c->fdm_u;
+  if (!F.dist) { fdmu_apply(s, F, g, z, c->fdmu_t1.p, c->fdmu_t2.p, 2); return; }
+  // leading directions locally (the shared planes are transformed by both owners), then whole lines of the partitioned direction for this
+  // rank's column group: gather by an all-to-all, fused forward / scale / backward pass with the GLOBAL 1D eigenvectors, scatter back
+  const int dim = F.dim, N = F.n_ranks, r = F.rank, last = dim - 1, ku = c->k_u;
+  const int nl = F.nn[last];
+  fdmu_apply(s, F, g, z, c->fdmu_t1.p, c->fdmu_t2.p, 0);
+  double *cur = dim == 3 ? c->fdmu_t2.p : c->fdmu_t1.p;
+  auto ncols_of = [&](int q) { return std::max<int64_t>(0, std::min<int64_t>(F.C, F.ncol_total - (int64_t)q * F.C)); };
+  auto own_of = [&](int q) { return ku * F.layers[q] + (q == N - 1 ? 1 : 0); };
+  const int64_t blk1 = (int64_t)dim * F.max_own * F.C;
+  for (int q = 0; q < N; ++q) fdmu_window(s, F.sendbuf.p + (size_t)q * blk1, cur, true, dim, own_of(r), F.max_own, F.C, ncols_of(q), F.ncol_total, nl, (int64_t)q * F.C, 0);
+  alltoall_blocks(c, F.sendbuf.p, F.recvbuf.p, blk1);
+  PORO_HIP(hipMemsetAsync(F.tz1.p, 0, (size_t)dim * F.ng * F.C * sizeof(double), s));
+  for (int q = 0; q < N; ++q) fdmu_window(s, F.tz1.p, F.recvbuf.p + (size_t)q * blk1, false, dim, own_of(q), F.max_own, F.C, F.C, F.C, F.ng, 0, F.off[q]);
+  fdmu_lines(s, F, F.last_global, F.C, (int64_t)r * F.C, ncols_of(r), F.tz1.p, F.tz2.p);
+  const int64_t blk2 = (int64_t)dim * F.max_nl * F.C;
+  for (int q = 0; q < N; ++q) fdmu_window(s, F.sendbuf.p + (size_t)q * blk2, F.tz2.p, true, dim, ku * F.layers[q] + 1, F.max_nl, F.C, F.C, F.C, F.ng, 0, F.off[q]);
+  alltoall_blocks(c, F.sendbuf.p, F.recvbuf.p, blk2);
+  for (int q = 0; q < N; ++q) fdmu_window(s, cur, F.recvbuf.p + (size_t)q * blk2, false, dim, nl, F.max_nl, F.C, ncols_of(q), F.ncol_total, nl, (int64_t)q * F.C, 0);
+  fdmu_apply(s, F, g, z, c->fdmu_t1.p, c->fdmu_t2.p, 1);
 }
 
 void setup(poro_ctx *c, const poro_desc *d) {

@@ -515,6 +515,24 @@ template <class TC> static void fdmu_apply_t(hipStream_t s, const FdmU &F, const
     }
   }
 }
+// copy a (component, planes, columns) window between a planar grid array [c][grid_planes][grid_stride] and a dense, zero-padded block
+// [c][n_planes_pad][C] (to_block) or back: the pieces of the all-to-all that hands whole lines of the partitioned direction to a rank
+__global__ void k_fdmu_window(double *dst, const double *src, int to_block, int ncomp, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid,
+                              int64_t grid_stride, int64_t grid_planes, int64_t grid_col0, int64_t grid_plane0) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)ncomp * n_planes_pad * C) return;
+  const int64_t cc = idx % C, rest = idx / C, k = rest % n_planes_pad, comp = rest / n_planes_pad;
+  const bool valid = k < n_planes && cc < ncols_valid;
+  const int64_t g = (comp * grid_planes + grid_plane0 + k) * grid_stride + grid_col0 + cc;
+  if (to_block) dst[idx] = valid ? src[g] : 0.0;
+  else if (valid) dst[g] = src[idx];
+}
+void fdmu_window(hipStream_t s, double *dst, const double *src, bool to_block, int ncomp, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid,
+                 int64_t grid_stride, int64_t grid_planes, int64_t grid_col0, int64_t grid_plane0) {
+  const int64_t n = (int64_t)ncomp * n_planes_pad * C;
+  if (n) hipLaunchKernelGGL(k_fdmu_window, (unsigned)((n + 255) / 256), 256, 0, s, dst, src, to_block ? 1 : 0, ncomp, n_planes, n_planes_pad, C, ncols_valid, grid_stride, grid_planes, grid_col0, grid_plane0);
+}
+
 void fdmu_apply(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1, void *t2, int stage) {
   if (F.single) fdmu_apply_t<float>(s, F, g, z, t1, t2, stage); else fdmu_apply_t<double>(s, F, g, z, t1, t2, stage);
 }

@@ -43,7 +43,9 @@ def main():
         tr, _ = O.run(1, REF["p_init"], REF["dt"], max_it=20000, prec=oracle_py.PREC_JACOBI)
         noconv = O.noconvergence_count()
     else:
-        R = pk.Runner(P, device=0, operator_mode=pk.OP_MATRIX_FREE if backend == "hip_mf" else pk.OP_CSR, p_init=REF["p_init"], dt=REF["dt"], max_it=20000)
+        # hip_mf_fdm: the displacement solve uses the block fast-diagonalisation preconditioner (all-to-all of column groups in the partitioned direction)
+        R = pk.Runner(P, device=0, operator_mode=pk.OP_CSR if backend == "hip_csr" else pk.OP_MATRIX_FREE, p_init=REF["p_init"], dt=REF["dt"], max_it=20000,
+                      prec=pk.PREC_FDM if backend == "hip_mf_fdm" else pk.PREC_JACOBI)
         O = R.ctx
         O.comm_callbacks(allreduce, sendrecv)
         R.initialize()

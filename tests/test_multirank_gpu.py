@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world,dim,n,deg,backend", [(2, 3, (3, 3, 6), 2, "hip_mf"), (2, 3, (4, 4, 6), 1, "hip_csr"), (2, 2, (8, 12), 2, "hip_mf"),
-                                                      (3, 3, (4, 5, 7), 1, "hip_mf"), (3, 2, (9, 10), 2, "hip_mf"), (4, 3, (3, 3, 9), 2, "hip_mf")])
+                                                      (3, 3, (4, 5, 7), 1, "hip_mf"), (3, 2, (9, 10), 2, "hip_mf"), (4, 3, (3, 3, 9), 2, "hip_mf"),
+                                                      (2, 3, (3, 4, 6), 2, "hip_mf_fdm"), (3, 2, (9, 10), 2, "hip_mf_fdm"), (3, 3, (4, 5, 7), 1, "hip_mf_fdm"), (4, 3, (5, 3, 9), 2, "hip_mf_fdm")])
 def test_ranks_on_one_gpu(tmp_path, world, dim, n, deg, backend):
     """2 and 3 ranks (uneven slabs, column groups that do not divide evenly): halo exchange, all-reduced dots, and the distributed
     fast-diagonalisation solves of the pressure / projection systems (all-to-all of column groups)."""
@@ -40,6 +41,8 @@ def test_ranks_on_one_gpu(tmp_path, world, dim, n, deg, backend):
     for r in R:
         assert np.array_equal(r["trace"][1:, :3], tr[1:, :3])
         assert np.all(r["trace"][1:, 7] <= 2 * np.maximum(r["trace"][1:, 2], 1))      # exact preconditioner: <= 2 CG iterations per pressure solve
+        if backend.endswith("_fdm"):
+            assert 0 < r["trace"][1:, 6].max() <= 40                                  # block fast diagonalisation of the displacement system
     u = stitch([r["u"] for r in R], off_u, plane_u, P.desc.n_dofs_u)
     p = stitch([r["p"] for r in R], off_p, plane_p, P.desc.n_dofs_p)
     rhs = stitch([r["rhs_u"] for r in R], off_u, plane_u, P.desc.n_dofs_u)
@@ -70,6 +73,12 @@ def test_rccl_data_plane_single_rank(monkeypatch):
         assert O.disp_solve()[0] == 0 and G.disp_solve(max_iter=5000)[0] == 0
         assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
         assert abs(G.norm(pk.VEC_U)[0] - np.linalg.norm(O.get(pk.VEC_U))) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+        # block fast diagonalisation of the displacement system through the partitioned path (RCCL all-reduce of the face flags / slab sizes, self block of the all-to-all)
+        assert G.supports_preconditioner(0, pk.PREC_FDM)
+        G.fill(pk.VEC_U, 0.0)
+        rc, info = G.disp_solve(max_iter=200, prec=pk.PREC_FDM)
+        assert rc == 0 and info.iterations <= 40
+        assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
         # the distributed fast-diagonalisation solve with RCCL as the communicator (1 rank: all-reduce + the self block of the all-to-all)
         assert G.supports_preconditioner(1, pk.PREC_FDM)
         for S in (O, G):
