@@ -12,8 +12,10 @@ enqueues behind the finishing iteration are no-ops), the Jacobian only when dt c
 
 Workload: 3D Q2/Q1 uniform box of 72^3 cells (N_u = 9 145 875: BASELINE config "3D Q2/Q1 ~10M DoF").  N > 1 cuts THAT mesh into N z-slabs
 (strong scaling: 9 cell layers per GPU at N = 8); the weak-scaled variant (72 layers per GPU, 72 x 72 x 72N box, same h) is measured
-as well and reported under "weak_scaling_line".  Every timed step must do a real displacement solve: the CG stops on the reduction of the
-step's own initial residual (PORO_STOP_REDUCTION), the per-step iteration counts are printed and a step with 0 iterations fails the run.
+as well and reported under "weak_scaling_line".  Every timed step must do a real displacement solve: by default each timed step is time
+step 1 from the initial equilibrium (the device state is rolled back before every step, so all steps do the same work whatever --steps /
+--warmup are; --transient times consecutive steps instead), the CG stops on the reduction of the step's own initial residual
+(PORO_STOP_REDUCTION), the per-step iteration counts are printed and a step with 0 iterations fails the run.
 Input is synthetic in the sense of SURVEY 8d: the bundled input.data material / BC values on a generated mesh.
 """
 import argparse
@@ -165,7 +167,12 @@ def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist,
             dist.barrier()
 
     R.initialize()                            # PoroelasticityFSS.h:308-317 (initial equilibrium; not part of a step)
+    repeat = not args.transient
+    if repeat:
+        R.save_state()                        # every step below is "time step 1 from the initial equilibrium": a device-side rollback (~30 us of copies, inside the timed region)
     for _ in range(warmup):
+        if repeat:
+            R.restore_state()
         R.step()
     before = R.work()
     G.timers_reset()                          # HIP events around every kernel family on the launch stream
@@ -173,7 +180,10 @@ def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist,
     t0 = time.perf_counter()
     traces, step_seconds = [], []
     for _ in range(steps):
-        ts = time.perf_counter(); traces.append(R.step()[0]); step_seconds.append(time.perf_counter() - ts)   # step() returns after a stream sync
+        ts = time.perf_counter()
+        if repeat:
+            R.restore_state()
+        traces.append(R.step()[0]); step_seconds.append(time.perf_counter() - ts)   # step() returns after a stream sync
     sync()
     elapsed = time.perf_counter() - t0
     after = R.work()
@@ -204,6 +214,9 @@ def main():
     ap.add_argument("--stop", choices=["reduction", "rhs"], default="reduction",
                     help="displacement CG stops at rel_tol x (reduction: the residual of the step's warm start | rhs: ||b||); with `rhs` a slow transient lets later steps accept the warm start")
     ap.add_argument("--rel-tol", type=float, default=1e-8, help="displacement CG: recursive residual <= max(1e-12, rel_tol * reference norm of --stop)")
+    ap.add_argument("--transient", action="store_true",
+                    help="time consecutive steps of the transient (BASELINE config 5) instead of repeating time step 1: the steps then differ (the input.data well rate is tiny, "
+                         "the transient dies within ~10 steps) and ms_per_step depends on the window")
     ap.add_argument("--max-iter", type=int, default=50000)
     ap.add_argument("--cpu-n", type=int, default=9, help="cells per direction of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -283,7 +296,7 @@ def main():
             "metric": "DoF-updates/sec in assemble+SpMV per fixed-stress iter", "value": updates / elapsed, "unit": "DoF-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{dim}D Q{deg}/Q1 uniform box, {'x'.join(map(str, n))} cells, N_u={n_u_glob}, N_p={n_p_glob}; one time step = one fixed-stress iteration "
+            "config": {"workload": f"{dim}D Q{deg}/Q1 uniform box, {'x'.join(map(str, n))} cells, N_u={n_u_glob}, N_p={n_p_glob}; {'consecutive time steps' if args.transient else 'time step 1 repeated (device-side rollback before each step)'}; one time step = one fixed-stress iteration "
                                    f"(pressure loop + matrix-free Jacobi-PCG displacement solve + strain projection); input.data material/BCs, z-face BCs per SURVEY Q9",
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU", "operator": "matrix_free",
                        "stopping_rule_u": stop_txt},

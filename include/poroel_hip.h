@@ -198,6 +198,12 @@ int  poro_vec_copy(poro_ctx *ctx, int dst, int src);               /* e.g. old_s
 int  poro_vec_axpy(poro_ctx *ctx, int y, double a, int x);         /* solution += solution_update (:379)                    */
 int  poro_vec_norm(poro_ctx *ctx, int which, double *l2, double *linf);
 
+/* device-side snapshot of every PORO_VEC_* vector (one slot) and its restoration: lets a caller retry a time step (e.g. with another dt) or
+ * repeat one for measurements without moving the state across PCIe; the reference has no counterpart (its only persistence is the per-step VTK dump,
+ * PoroelasticityFSS.h:286-290). */
+int  poro_state_save(poro_ctx *ctx);
+int  poro_state_restore(poro_ctx *ctx);
+
 /* PoroElasticDisplacementSolver<dim>::assemble_system (:155-291); pressure taken from PORO_VEC_P.
  * rebuild_matrix mirrors `rebuild_system_matrix` (:280): 1 = (re)build A_u (CSR values, or the
  * matrix-free operator data + diagonal) and the constant Dirichlet lifting, 0 = RHS only. */

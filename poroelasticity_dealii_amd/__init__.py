@@ -83,7 +83,7 @@ SENDRECV_FN = C.CFUNCTYPE(None, _dp, _dp, C.c_int64, C.c_int32, C.c_void_p)
 HIP_SYMBOLS = [
     "poro_last_error", "poro_abi_version", "poro_ctx_create", "poro_ctx_destroy", "poro_comm_unique_id", "poro_ctx_comm_init_rccl",
     "poro_ctx_comm_init_callbacks", "poro_vec_set", "poro_vec_get", "poro_vec_fill", "poro_vec_copy", "poro_vec_axpy", "poro_vec_norm",
-    "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_assemble_jacobian", "poro_pres_solve",
+    "poro_state_save", "poro_state_restore", "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_assemble_jacobian", "poro_pres_solve",
     "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain", "poro_get_effective_stresses",
     "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_apply_preconditioner_u", "poro_bench_operator", "poro_timers_reset", "poro_timers_enable", "poro_timers_get"]
 
@@ -116,6 +116,8 @@ def load_hip():
         L.poro_vec_axpy.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
         L.poro_vec_norm.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.poro_disp_assemble_system.argtypes = [C.c_void_p, C.c_int]
+        L.poro_state_save.argtypes = [C.c_void_p]
+        L.poro_state_restore.argtypes = [C.c_void_p]
         L.poro_disp_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]
         L.poro_supports_preconditioner.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.poro_pres_assemble_residual.argtypes = [C.c_void_p, C.c_double, _dp]
@@ -167,6 +169,7 @@ def load_host():
         L.poro_host_runner_work.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.poro_host_runner_work.restype = None
         L.poro_host_runner_postprocess.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.poro_host_runner_state.argtypes = [C.c_void_p, C.c_int]
         L.poro_host_runner_free.argtypes = [C.c_void_p]
         L.poro_host_runner_free.restype = None
         _host = L
@@ -280,6 +283,12 @@ class Context:
         a, b = C.c_double(), C.c_double()
         self._chk(self.L.poro_vec_norm(self.ptr, which, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def state_save(self):
+        self._chk(self.L.poro_state_save(self.ptr))
+
+    def state_restore(self):
+        self._chk(self.L.poro_state_restore(self.ptr))
 
     def disp_assemble_system(self, rebuild=True):
         self._chk(self.L.poro_disp_assemble_system(self.ptr, int(rebuild)))
@@ -432,6 +441,15 @@ class Runner:
         if rows < 0:
             raise RuntimeError(self.H.poro_host_last_error().decode())
         return trace[:rows], dict(zip(WORK_FIELDS, list(work)))
+
+    def save_state(self):
+        """device-side snapshot of every solver vector (and the step counter)"""
+        if self.H.poro_host_runner_state(self.h, 0) != 0:
+            raise RuntimeError(self.H.poro_host_last_error().decode())
+
+    def restore_state(self):
+        if self.H.poro_host_runner_state(self.h, 1) != 0:
+            raise RuntimeError(self.H.poro_host_last_error().decode())
 
     def postprocess(self, output_dir=None, corrected=False):
         """PoroelasticityFSS.h:409-411: shear strains, effective stresses (PORO_VEC_STRESS0+e) and, with a directory, solution-NNNN.vtk"""

@@ -128,7 +128,7 @@ struct poro_ctx {
   bool projection_matrix_ready = false;
   poro::DevBuf<double> Ke;                   // reference element matrix of the matrix-free operator
   // vectors (ids of include/poroel_hip.h)
-  std::map<int, poro::DevBuf<double>> vec;
+  std::map<int, poro::DevBuf<double>> vec, vec_saved;
   poro::DevBuf<double> lift_u, neumann_u, diag_u, diag_u_local, diag_J, diag_M, src_local;
   poro::DevBuf<double> dinv_u, dinv_J, dinv_M;   // reciprocals of the Jacobi diagonals
   poro::DevBuf<uint8_t> diag_u_cls; poro::DevBuf<double> diag_u_tab;   // dictionary form of diag_u (uniform boxes): class per node + table[class][dim]

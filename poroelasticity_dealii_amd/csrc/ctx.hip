@@ -900,6 +900,22 @@ int poro_vec_norm(poro_ctx *c, int which, double *l2, double *linf) {
   });
 }
 
+int poro_state_save(poro_ctx *c) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    for (auto &kv : c->vec) { DevBuf<double> &d = c->vec_saved[kv.first]; if (d.n != kv.second.n) d.alloc(kv.second.n); la_copy(c->stream, d.p, kv.second.p, (int64_t)kv.second.n); }
+    PORO_HIP(hipStreamSynchronize(c->stream)); return 0;
+  });
+}
+int poro_state_restore(poro_ctx *c) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    if (c->vec_saved.empty()) throw Error("state_restore without state_save");
+    for (auto &kv : c->vec_saved) la_copy(c->stream, c->vec.at(kv.first).p, kv.second.p, (int64_t)kv.second.n);
+    return 0;
+  });
+}
+
 int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));

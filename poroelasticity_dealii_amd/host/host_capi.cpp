@@ -138,6 +138,15 @@ int poro_host_runner_step(void *r, double *trace, int max_rows, int64_t *work) {
     return rows;
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+// action 0: snapshot the device state, 1: roll back to it
+int poro_host_runner_state(void *r, int action) {
+  try {
+    auto *R = static_cast<HostRunner *>(r);
+    if (R->dim == 2) { if (action) R->p2->restore_state(); else R->p2->save_state(); }
+    else { if (action) R->p3->restore_state(); else R->p3->save_state(); }
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 // tail of the time loop body (PoroelasticityFSS.h:409-411): shear strains, effective stresses and, with a directory, solution-NNNN.vtk
 int poro_host_runner_postprocess(void *r, const char *output_dir, int corrected) {
   try {

@@ -296,6 +296,9 @@ template <int dim> class PoroElasticProblem {
     }
     return rows;
   }
+  // device-side snapshot / rollback of the whole solver state (retry or repeat a time step)
+  void save_state() { check(poro_state_save(ctx), "state_save"); saved_step_number = time_step_number; }
+  void restore_state() { check(poro_state_restore(ctx), "state_restore"); time_step_number = saved_step_number; }
   int run(const RunControls &rc, double *trace, int max_rows) {
     int rows = 0;
     initialize(rc);
@@ -320,7 +323,7 @@ template <int dim> class PoroElasticProblem {
   void normal_strains() {
     get_normal_strain_components(); work.proj_rhs++;
   }
-  bool first_assembly = true; int time_step_number = 0; double jacobian_dt = -1;
+  bool first_assembly = true; int time_step_number = 0, saved_step_number = 0; double jacobian_dt = -1;
   const ProblemData *pd;
   static poro_ctx *make_ctx(ProblemData &P, int device, int operator_mode) {
     poro_ctx *c = nullptr;

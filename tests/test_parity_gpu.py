@@ -156,7 +156,7 @@ def test_fast_diagonalisation_preconditioner(pair):
     (StrainProjector.h:101-106) are Kronecker sums; the preconditioner is their exact inverse, so SolverCG stops after one or
     two iterations on the same solution the oracle's SSOR-CG converges to."""
     P, O, G = pair
-    assert G.supports_preconditioner(1, pk.PREC_FDM) and not G.supports_preconditioner(0, pk.PREC_FDM)
+    assert G.supports_preconditioner(1, pk.PREC_FDM) and G.supports_preconditioner(0, pk.PREC_FDM)
     n = G.n_p
     vals = {pk.VEC_P: 10e6 * (1 + 0.05 * synth(n)), pk.VEC_P_OLD: 10e6 * (1 + 0.05 * synth(n, 0.2)), pk.VEC_EPSV: -2e-6 * (1 + 0.3 * synth(n, 0.5)),
             pk.VEC_EPSV0: -2e-6 * np.ones(n)}
@@ -177,8 +177,12 @@ def test_fast_diagonalisation_preconditioner(pair):
         rc0, _ = O.proj_solve(e, rel_tol=1e-13); rc, info = G.proj_solve(e, rel_tol=1e-8, prec=pk.PREC_FDM)
         assert rc0 == 0 and rc == 0 and info.iterations <= 2
         assert rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
-    with pytest.raises(RuntimeError, match="pressure / projection"):
-        G.disp_assemble_system(True); G.disp_solve(prec=pk.PREC_FDM)
+    # the displacement system's block form (tests/test_fdm_u_gpu.py) also serves the assembled-CSR operator
+    O.disp_assemble_system(True); G.disp_assemble_system(True)
+    O.fill(pk.VEC_U, 0.0); G.fill(pk.VEC_U, 0.0)
+    rc0, _ = O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=5000); rc, info = G.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=100, prec=pk.PREC_FDM)
+    assert rc0 == 0 and rc == 0 and info.iterations <= 40
+    assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-9
 
 
 def test_fast_diagonalisation_needs_a_box():
