@@ -97,6 +97,21 @@ typedef struct poro_partition {
   int64_t plane_p;   /* p dofs on one interface plane  */
 } poro_partition;
 
+/* Closed affine constraints beyond the Dirichlet list: the hanging nodes of a locally refined mesh (DoFTools::make_hanging_node_constraints,
+ * PoroElasticDisplacementSolver.h:112-113, PoroElasticPressureSolver.h:72-75; refine_mesh, PoroelasticityFSS.h:447-498).
+ *   x[dof[i]] = sum_{k in ptr[i]..ptr[i+1]} weight[k] * x[master[k]] + inhomogeneity[i]
+ * exactly what ConstraintMatrix holds after close(): masters are unconstrained dofs, a constrained dof appears once and is not in the
+ * Dirichlet list.  The library condenses at operator level (C^T A C on the free dofs, C^T b), which gives the same solution as
+ * ConstraintMatrix::condense / distribute_local_to_global (:153, :168, PoroElasticDisplacementSolver.h:280-286), and distributes after each solve (:180, :306). */
+typedef struct poro_constraints {
+  int64_t n;
+  const int32_t *dof;            /* [n]      */
+  const int64_t *ptr;            /* [n+1]    */
+  const int32_t *master;         /* [ptr[n]] */
+  const double  *weight;         /* [ptr[n]] */
+  const double  *inhomogeneity;  /* [n]      */
+} poro_constraints;
+
 typedef struct poro_desc {
   int32_t abi_version;
   int32_t dim;        /* 2 | 3 */
@@ -122,6 +137,8 @@ typedef struct poro_desc {
   poro_material   mat;
   poro_structured box;
   poro_partition  part;
+  poro_constraints cons_u;   /* displacement space (n = 0: none) */
+  poro_constraints cons_p;   /* pressure space; also used by the strain projection (StrainProjector.h:191-194) */
 } poro_desc;
 
 /* Krylov controls.  Reference values: displacement abs 1e-12, 1000 its

@@ -230,6 +230,27 @@ struct Comm {
 
 struct SolveInfo { int iterations = 0; int converged = 0; double r0 = 0, r = 0; };
 
+// Closed ConstraintMatrix beyond the Dirichlet list: hanging nodes (DoFTools::make_hanging_node_constraints, PoroElasticDisplacementSolver.h:112-113,
+// PoroElasticPressureSolver.h:72-75).  deal.II condenses the assembled system (condense / distribute_local_to_global, PoroElasticPressureSolver.h:153,168,
+// PoroElasticDisplacementSolver.h:280-286); on the unconstrained dofs that system is C^T A C x = C^T (b - A x_inh), x = C x_free + x_inh, which is
+// what expand / reduce below apply around the unconstrained operator; distribute (:180, :306) fills the constrained entries afterwards.
+struct Cons {
+  std::vector<int32_t> dof, master; std::vector<int64_t> ptr; Vec weight, inhom;
+  void init(const poro_constraints &c) {
+    if (c.n <= 0) return;
+    dof.assign(c.dof, c.dof + c.n); ptr.assign(c.ptr, c.ptr + c.n + 1); inhom.assign(c.inhomogeneity, c.inhomogeneity + c.n);
+    if (ptr[c.n]) { master.assign(c.master, c.master + ptr[c.n]); weight.assign(c.weight, c.weight + ptr[c.n]); }
+  }
+  bool any() const { return !dof.empty(); }
+  void expand(Vec &x, bool with_inhom) const {           // ConstraintMatrix::distribute
+    for (size_t i = 0; i < dof.size(); ++i) { double s = with_inhom ? inhom[i] : 0.0; for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) s += weight[k] * x[master[k]]; x[dof[i]] = s; }
+  }
+  void reduce(Vec &y) const {                            // ConstraintMatrix::condense(vector)
+    for (size_t i = 0; i < dof.size(); ++i) { for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) y[master[k]] += weight[k] * y[dof[i]]; }
+    for (size_t i = 0; i < dof.size(); ++i) y[dof[i]] = 0.0;
+  }
+};
+
 struct Oracle {
   poro_desc d; int dim, k_u, ns_u, ns_p, dpc_u, dpc_p, nv;
   std::vector<double> vx; std::vector<int32_t> cv, cdu, cdp, bfc, bfl, bfi, ddof, nlab, ncomp; Vec dval, nval;
@@ -246,6 +267,7 @@ struct Oracle {
   Vec eps_v, eps_v0;
   int tensor_to_entry[9];
   int64_t work[6] = {0, 0, 0, 0, 0, 0};   // apply_u, apply_p, asm_rhs_u, residual_p, jacobian_p, proj_rhs (same units as the host driver's counters)
+  Cons cons_u, cons_p;      // hanging-node constraints of the two spaces (empty on uniform meshes)
   int stop_rule_u = 0;      // stopping rule of the displacement solve (see cg)
   int n_noconvergence = 0;  // SolverControl::NoConvergence would have been thrown this many times
 
@@ -260,6 +282,7 @@ struct Oracle {
     ddof.assign(d.dirichlet_dof, d.dirichlet_dof + d.n_dirichlet); dval.assign(d.dirichlet_value, d.dirichlet_value + d.n_dirichlet);
     nlab.assign(d.neumann_label, d.neumann_label + d.n_neumann); ncomp.assign(d.neumann_component, d.neumann_component + d.n_neumann); nval.assign(d.neumann_value, d.neumann_value + d.n_neumann);
     mat = d.mat; comm.part = d.part;
+    cons_u.init(d.cons_u); cons_p.init(d.cons_p);
     // TensorIndexer.h:18-35
     if (dim == 2) { const int t[4] = {0, 1, 1, 2}; std::copy(t, t + 4, tensor_to_entry); }
     else { const int t[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5}; std::copy(t, t + 9, tensor_to_entry); }
@@ -411,19 +434,31 @@ struct Oracle {
     rebuild_system_matrix = false;                                   // :290
     work[2]++;
     comm.exchange_add(rhs_u, d.part.plane_u);
+    if (cons_u.any()) {                                              // hanging-node part of distribute_local_to_global (:280-286): C^T (b - A x_inh)
+      Vec xin(d.n_dofs_u, 0.0), t(d.n_dofs_u, 0.0); cons_u.expand(xin, true);
+      A.vmult(t, xin);
+      for (int64_t i = 0; i < d.n_dofs_u; ++i) if (!is_dir[i]) rhs_u[i] -= t[i];
+      cons_u.reduce(rhs_u);
+    }
   }
 
   // SolverCG<>::solve with PreconditionSSOR (deal.II 8.4 semantics); prec: 0 none, 1 Jacobi, 2 SSOR(omega).
   // Multi-rank: the local matrix holds this slab's partial rows; shared-plane rows are completed by exchange_add.
   // stop_rule 0: ||g|| <= max(abs_tol, rel_tol ||b||) (the reference's SolverControl objects); 1: rel_tol against the residual of the warm
   // start (deal.II ReductionControl) - the stated rule of the transient benchmark, mirrored from include/poroel_hip.h PORO_STOP_REDUCTION
-  SolveInfo cg(const Csr &M, Vec &x, const Vec &b, double abs_tol, double rel_tol, int max_iter, int prec, double omega, int64_t plane, int stop_rule = 0) {
-    const int64_t n = M.n; Vec g(n), dvec(n), h(n), diagv;
+  SolveInfo cg(const Csr &M, Vec &x, const Vec &b, double abs_tol, double rel_tol, int max_iter, int prec, double omega, int64_t plane, int stop_rule = 0, const Cons *cons = nullptr) {
+    const int64_t n = M.n; Vec g(n), dvec(n), h(n), diagv, tmp;
+    if (cons && !cons->any()) cons = nullptr;
+    if (cons && prec == 2) prec = 1;   // the condensed matrix exists at operator level only: Jacobi instead of the SSOR sweeps
     SolveInfo info;
     int64_t &napply = work[&M == &A ? 0 : 1];
     if (prec == 1 || comm.multi()) { diagv.resize(n); for (int64_t r = 0; r < n; ++r) diagv[r] = M.val[M.diag[r]]; comm.exchange_add(diagv, plane); }
     if (comm.multi() && prec == 2) prec = 1;  // SSOR is rank-local-order dependent; multi-rank oracle uses Jacobi
-    auto apply = [&](Vec &y, const Vec &v) { M.vmult(y, v); comm.exchange_add(y, plane); ++napply; };
+    auto apply = [&](Vec &y, const Vec &v) {
+      if (cons) { tmp = v; cons->expand(tmp, false); M.vmult(y, tmp); cons->reduce(y); }
+      else M.vmult(y, v);
+      comm.exchange_add(y, plane); ++napply;
+    };
     auto precond = [&](Vec &y, const Vec &v) {
       if (prec == 2) M.precondition_ssor(y, v, omega);
       else if (prec == 1) for (int64_t r = 0; r < n; ++r) y[r] = v[r] / diagv[r];
@@ -456,8 +491,9 @@ struct Oracle {
 
   // PoroElasticDisplacementSolver::solve :294-307
   SolveInfo disp_solve(double abs_tol, double rel_tol, int max_iter, int prec, double omega) {
-    SolveInfo s = cg(A, u, rhs_u, abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_u, stop_rule_u);
+    SolveInfo s = cg(A, u, rhs_u, abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_u, stop_rule_u, &cons_u);
     for (size_t i = 0; i < ddof.size(); ++i) u[ddof[i]] = dval[i];    // constraints.distribute :306
+    cons_u.expand(u, true);
     return s;
   }
 
@@ -488,6 +524,7 @@ struct Oracle {
     comm.exchange_add(residual, d.part.plane_p);
     well_source(source);                                                                            // :142-147
     for (int64_t i = 0; i < n; ++i) { residual[i] += source[i]; residual[i] *= -1; }                 // :148,152
+    cons_p.reduce(residual);                                                                        // constraints.condense(residual) :153
     work[3]++;
     return std::sqrt(comm.dot(residual, residual, d.part.plane_p));                                 // PoroelasticityFSS.h:364
   }
@@ -498,7 +535,9 @@ struct Oracle {
   }
   // PoroElasticPressureSolver::solve :172-185
   SolveInfo pres_solve(double abs_tol, double rel_tol, int max_iter, int prec, double omega) {
-    return cg(Jp, dp, residual, abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_p);
+    SolveInfo s = cg(Jp, dp, residual, abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_p, 0, &cons_p);   // condensed Jacobian :168
+    cons_p.expand(dp, true);                                                                        // constraints.distribute :180
+    return s;
   }
   // PoroElasticPressureSolver::update_volumetric_strain :187-194
   void update_volumetric_strain() {
@@ -532,11 +571,13 @@ struct Oracle {
       for (int c = 0; c < ncomp_; ++c) for (int i = 0; i < dpc_p; ++i) proj_rhs[tensor_to_entry[comps[c]]][cdp[cell * dpc_p + i]] += cell_rhs[c][i];   // :191-194
     }
     work[5]++;
-    for (int c = 0; c < ncomp_; ++c) comm.exchange_add(proj_rhs[tensor_to_entry[comps[c]]], d.part.plane_p);
+    for (int c = 0; c < ncomp_; ++c) { comm.exchange_add(proj_rhs[tensor_to_entry[comps[c]]], d.part.plane_p); cons_p.reduce(proj_rhs[tensor_to_entry[comps[c]]]); }   // :191-194 through the pressure constraints
   }
   // StrainProjector::solve_projection_system :201-232
   SolveInfo proj_solve(int entry, double abs_tol, double rel_tol, int max_iter, int prec, double omega) {
-    return cg(Pm, strains[entry], proj_rhs[entry], abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_p);
+    SolveInfo s = cg(Pm, strains[entry], proj_rhs[entry], abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_p, 0, &cons_p);
+    cons_p.expand(strains[entry], true);                                                            // constraints.distribute :216
+    return s;
   }
   // PoroElasticProblem::get_volumetric_strain PoroelasticityFSS.h:179-186
   void get_volumetric_strain() {

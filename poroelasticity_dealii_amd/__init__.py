@@ -42,6 +42,10 @@ class Partition(C.Structure):
     _fields_ = [("rank", C.c_int32), ("n_ranks", C.c_int32), ("has_lower", C.c_int32), ("has_upper", C.c_int32), ("plane_u", C.c_int64), ("plane_p", C.c_int64)]
 
 
+class Constraints(C.Structure):
+    _fields_ = [("n", C.c_int64), ("dof", _ip), ("ptr", C.POINTER(C.c_int64)), ("master", _ip), ("weight", _dp), ("inhomogeneity", _dp)]
+
+
 class Desc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("dim", C.c_int32), ("degree_u", C.c_int32), ("degree_p", C.c_int32),
                 ("n_cells", C.c_int64), ("n_vertices", C.c_int64), ("n_dofs_u", C.c_int64), ("n_dofs_p", C.c_int64),
@@ -50,7 +54,7 @@ class Desc(C.Structure):
                 ("n_bfaces", C.c_int64), ("bface_cell", _ip), ("bface_local", _ip), ("bface_id", _ip),
                 ("n_dirichlet", C.c_int64), ("dirichlet_dof", _ip), ("dirichlet_value", _dp),
                 ("n_neumann", C.c_int32), ("neumann_label", _ip), ("neumann_component", _ip), ("neumann_value", _dp),
-                ("mat", Material), ("box", Structured), ("part", Partition)]
+                ("mat", Material), ("box", Structured), ("part", Partition), ("cons_u", Constraints), ("cons_p", Constraints)]
 
 
 class SolverOpts(C.Structure):
@@ -151,6 +155,8 @@ def load_host():
         bc = [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, C.POINTER(Material)]
         L.poro_host_build_box.restype = C.c_void_p
         L.poro_host_build_box.argtypes = [C.c_int, _ip, _dp, C.c_int, C.c_int, C.c_int] + bc
+        L.poro_host_build_refined_box.restype = C.c_void_p
+        L.poro_host_build_refined_box.argtypes = [C.c_int, _ip, _dp, C.c_int, _ip, _ip] + bc
         L.poro_host_build_gmsh.restype = C.c_void_p
         L.poro_host_build_gmsh.argtypes = [C.c_char_p, C.c_int] + bc
         L.poro_host_desc.restype = C.POINTER(Desc)
@@ -218,6 +224,17 @@ class Problem:
         n3, pn = _arr_i(list(n) + [1] * (3 - len(n)))
         s3, ps = _arr_d(list(size) + [1.0] * (3 - len(size)))
         return cls(load_host().poro_host_build_box(dim, pn, ps, degree_u, rank, n_ranks, *args, C.byref(material)))
+
+    @classmethod
+    def refined_box(cls, dim, n, size, degree_u, material, dirichlet, refine_lo, refine_hi, neumann=()):
+        """box of n[d] coarse cells whose cells with index in [refine_lo, refine_hi) are split once (2^dim children): a mesh with hanging nodes,
+        as one refine_mesh() pass of the reference produces (PoroelasticityFSS.h:447-498); the constraint lists come with the descriptor"""
+        keep, args = cls._bc(dirichlet, neumann)
+        n3, pn = _arr_i(list(n) + [1] * (3 - len(n)))
+        s3, ps = _arr_d(list(size) + [1.0] * (3 - len(size)))
+        lo, plo = _arr_i(list(refine_lo) + [0] * (3 - len(refine_lo)))
+        hi, phi = _arr_i(list(refine_hi) + [1] * (3 - len(refine_hi)))
+        return cls(load_host().poro_host_build_refined_box(dim, pn, ps, degree_u, plo, phi, *args, C.byref(material)))
 
     @classmethod
     def gmsh(cls, path, degree_u, material, dirichlet, neumann=()):

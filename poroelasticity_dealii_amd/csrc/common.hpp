@@ -88,6 +88,16 @@ struct CsrDev {
   SsorLevels ssor;
 };
 
+// closed affine constraints (hanging nodes) on the device: forward lists (constrained dof -> masters) for expand / distribute and the
+// transposed lists (master -> constrained dofs) so that the reduction C^T y is a gather without atomics
+struct ConsDev {
+  int64_t n = 0, n_masters = 0;
+  DevBuf<int32_t> dof, master; DevBuf<int64_t> ptr; DevBuf<double> weight, inhom;
+  DevBuf<int32_t> t_master, t_dof; DevBuf<int64_t> t_ptr; DevBuf<double> t_weight;
+  DevBuf<uint8_t> inert;   // byte mask: constrained (Dirichlet or hanging) dofs stay out of the Krylov system
+  bool any_inhom = false;
+};
+
 struct Timer { double seconds = 0; int64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
 
 struct Comm {
@@ -120,6 +130,7 @@ struct poro_ctx {
   std::vector<int64_t> color_off;            // host offsets into color_cells
   poro::DevBuf<uint8_t> dir_mask, node_mask; poro::DevBuf<double> dir_val; poro::DevBuf<int32_t> dir_dofs;
   std::vector<int32_t> h_dir_dof; std::vector<double> h_dir_val;
+  poro::ConsDev cons_u, cons_p;
   poro::DevBuf<int32_t> bface_cell, bface_local, bface_id, neu_label, neu_comp; poro::DevBuf<double> neu_val;
   int64_t n_bfaces = 0; int n_neumann = 0;
   // matrices
@@ -172,6 +183,10 @@ void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, dou
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag);
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n);
 void la_pointwise_mul(hipStream_t s, double *y, const double *x, int64_t n);   // y *= x
+// x[dof_i] = sum_k w_k x[master_k] (+ inhomogeneity_i): ConstraintMatrix::distribute; with_inhom = false inside the Krylov iteration
+void la_cons_expand(hipStream_t s, const ConsDev &C, double *x, bool with_inhom);
+// y <- C^T y: y[master] += sum w y[dof_i], then y[dof_i] = 0 (ConstraintMatrix::condense of a vector)
+void la_cons_reduce(hipStream_t s, const ConsDev &C, double *y);
 void la_xpby(hipStream_t s, double *y, double a, double b, const double *x, int64_t n);   // y = a y + b x
 void la_ilu_apply(hipStream_t s, const CsrDev &A, const double *lu, const SsorLevels &lv, const double *src, double *dst);
 void la_ssor_apply(hipStream_t s, const CsrDev &A, const double *val, const SsorLevels &lv, double omega, const double *src, double *dst);

@@ -634,6 +634,45 @@ void fdm_precondition_u(poro_ctx *c, const double *g, double *z) {
   fdmu_apply(s, F, g, z, c->fdmu_t1.p, c->fdmu_t2.p, 1);
 }
 
+// poro_constraints -> device lists (+ transposed lists for the gather form of C^T y); `fixed` = byte mask of the Dirichlet dofs of the same space (or null)
+void upload_constraints(ConsDev &C, const poro_constraints &h, int64_t n_dofs, const std::vector<uint8_t> *fixed, const char *what) {
+  C.n = h.n;
+  std::vector<uint8_t> inert(n_dofs, 0);
+  if (fixed) inert = *fixed;
+  if (h.n < 0) throw Error(std::string(what) + ": negative constraint count");
+  if (h.n == 0) { if (fixed) C.inert.upload(inert); return; }
+  if (!h.dof || !h.ptr || !h.inhomogeneity) throw Error(std::string(what) + ": null constraint arrays");
+  std::vector<uint8_t> hanging(n_dofs, 0);
+  for (int64_t i = 0; i < h.n; ++i) {
+    const int32_t dof = h.dof[i];
+    if (dof < 0 || dof >= n_dofs) throw Error(std::string(what) + ": constrained dof out of range");
+    if (hanging[dof]) throw Error(std::string(what) + ": dof constrained twice");
+    if (fixed && (*fixed)[dof]) throw Error(std::string(what) + ": dof is both in the Dirichlet list and in the constraint list");
+    hanging[dof] = 1;
+  }
+  const int64_t nm = h.ptr[h.n];
+  if (h.ptr[0] != 0 || nm < 0 || (nm && (!h.master || !h.weight))) throw Error(std::string(what) + ": bad constraint offsets");
+  std::map<int32_t, std::vector<std::pair<int32_t, double>>> tr;
+  for (int64_t i = 0; i < h.n; ++i) {
+    if (h.ptr[i + 1] < h.ptr[i]) throw Error(std::string(what) + ": constraint offsets not ascending");
+    for (int64_t k = h.ptr[i]; k < h.ptr[i + 1]; ++k) {
+      const int32_t m = h.master[k];
+      if (m < 0 || m >= n_dofs) throw Error(std::string(what) + ": master dof out of range");
+      if (hanging[m] || (fixed && (*fixed)[m])) throw Error(std::string(what) + ": constraints are not closed (a master is itself constrained)");
+      tr[m].emplace_back(h.dof[i], h.weight[k]);
+    }
+    if (h.inhomogeneity[i] != 0.0) C.any_inhom = true;
+  }
+  C.dof.upload(h.dof, h.n); C.ptr.upload(h.ptr, h.n + 1); C.inhom.upload(h.inhomogeneity, h.n);
+  if (nm) { C.master.upload(h.master, nm); C.weight.upload(h.weight, nm); }
+  std::vector<int32_t> tm, td; std::vector<int64_t> tp{0}; std::vector<double> tw;
+  for (auto &kv : tr) { tm.push_back(kv.first); for (auto &e : kv.second) { td.push_back(e.first); tw.push_back(e.second); } tp.push_back((int64_t)td.size()); }
+  C.n_masters = (int64_t)tm.size();
+  if (C.n_masters) { C.t_master.upload(tm); C.t_dof.upload(td); C.t_ptr.upload(tp); C.t_weight.upload(tw); }
+  for (int64_t i = 0; i < n_dofs; ++i) inert[i] = inert[i] | hanging[i];
+  C.inert.upload(inert);
+}
+
 void setup(poro_ctx *c, const poro_desc *d) {
   if (d->abi_version != PORO_ABI_VERSION) throw Error("poro_desc.abi_version mismatch");
   if (d->dim != 2 && d->dim != 3) throw Error("dim must be 2 or 3");
@@ -697,6 +736,13 @@ void setup(poro_ctx *c, const poro_desc *d) {
   { std::vector<uint8_t> m(c->n_u, 0); std::vector<double> v(c->n_u, 0.0);
     for (int64_t i = 0; i < d->n_dirichlet; ++i) { const int32_t dof = d->dirichlet_dof[i]; if (dof < 0 || dof >= c->n_u) throw Error("dirichlet_dof out of range"); m[dof] = 1; v[dof] = d->dirichlet_value[i]; }
     c->dir_mask.upload(m); c->dir_val.upload(v);
+    // hanging-node constraints (locally refined meshes): operator-level condensation, see include/poroel_hip.h poro_constraints
+    if (d->cons_u.n || d->cons_p.n) {
+      if (c->operator_mode != PORO_OP_CSR || d->box.enabled) throw Error("constraint lists need the assembled-CSR operator on a general (non-box) mesh");
+      if (c->comm.part.n_ranks > 1) throw Error("constraint lists are implemented for one rank");
+    }
+    upload_constraints(c->cons_u, d->cons_u, c->n_u, &m, "cons_u");
+    upload_constraints(c->cons_p, d->cons_p, c->n_p, nullptr, "cons_p");
     { std::vector<uint8_t> nm((size_t)(c->n_u / c->dim), 0); for (int64_t i = 0; i < d->n_dirichlet; ++i) nm[d->dirichlet_dof[i] / c->dim] |= (uint8_t)(1u << (d->dirichlet_dof[i] % c->dim)); c->node_mask.upload(nm); c->h_node_mask = std::move(nm); }
     if (d->n_dirichlet) c->dir_dofs.upload(d->dirichlet_dof, d->n_dirichlet);
     if (d->box.enabled) {   // are all constrained dofs on the box boundary?  (lets the matrix-free kernels skip mask loads in the interior)
@@ -976,7 +1022,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
       c->diag_u_cls.release(); c->diag_u_tab.release();
       if (!c->dinv_u.p) c->dinv_u.alloc(c->n_u);
       la_reciprocal(s, c->dinv_u.p, c->diag_u.p, c->n_u);
-      la_mask_zero(s, c->dinv_u.p, c->dir_mask.p, c->n_u);                       // zero reciprocal = inert Dirichlet dof (DiagVec)
+      la_mask_zero(s, c->dinv_u.p, c->cons_u.inert.p, c->n_u);                   // zero reciprocal = inert (Dirichlet or hanging) dof (DiagVec)
       if (c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled) {
         std::vector<double> hd(c->n_u);
         PORO_HIP(hipMemcpyAsync(hd.data(), c->dinv_u.p, c->n_u * sizeof(double), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
@@ -1005,6 +1051,17 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
       }
     }
     exchange_add(c, vec(c, PORO_VEC_RHS_U), c->n_u, c->comm.part.plane_u);
+    if (c->cons_u.n) {
+      // condensed right-hand side C^T (b - A x_inh), x_inh = the constraints' inhomogeneities (distribute_local_to_global, :280-286)
+      double *rhs = vec(c, PORO_VEC_RHS_U);
+      if (c->cons_u.any_inhom) {
+        la_fill(s, c->wd_u.p, 0.0, c->n_u); la_cons_expand(s, c->cons_u, c->wd_u.p, true);
+        la_csr_spmv(s, c->Au, c->Au_val.p, c->wd_u.p, c->wh_u.p);
+        la_mask_zero(s, c->wh_u.p, c->dir_mask.p, c->n_u);
+        la_axpy(s, rhs, -1.0, c->wh_u.p, c->n_u);
+      }
+      la_cons_reduce(s, c->cons_u, rhs);
+    }
     PORO_HIP(hipStreamSynchronize(s));
     return 0;
   });
@@ -1013,6 +1070,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
 int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec) {
   if (!c) return 0;
   if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
+  if (which_system == 0 ? c->cons_u.n : c->cons_p.n) return 0;   // condensed operators exist at operator level only: Jacobi
   if (prec == PORO_PREC_SSOR || prec == PORO_PREC_ILU0) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
   if (prec == PORO_PREC_FDM && which_system == 1) return fdm_p_supported(c);
   if (prec == PORO_PREC_FDM) { analyse_fdm_u(c); return c->fdm_u_state == 1; }
@@ -1023,6 +1081,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     PORO_HIP(hipSetDevice(c->device));
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
+    if (c->cons_u.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE) throw Error("meshes with hanging-node constraints: PORO_PREC_JACOBI / NONE only (the operator is condensed on the fly)");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       if (mode != PORO_OP_CSR) throw Error("PORO_PREC_ILU0 needs the assembled CSR operator");
       const int rc = pcg_ilu0(c, c->Au, c->Au_val.p, c->ilu_u, c->ilu_u_valid, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
@@ -1037,7 +1096,14 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       PORO_HIP(hipStreamSynchronize(c->stream));
       return rc;
     }
-    auto apply = [&](const double *x, double *y, double *dp) { return apply_A_u(c, x, y, mode, dp, false, dp ? c->scal.p : nullptr); };
+    const std::function<bool(const double *, double *, double *)> apply = [&](const double *x, double *y, double *dp) {
+      if (!c->cons_u.n) return apply_A_u(c, x, y, mode, dp, false, dp ? c->scal.p : nullptr);
+      // C^T A C: the search direction's hanging entries follow their masters, the product's hanging rows fold into the masters' rows
+      la_cons_expand(c->stream, c->cons_u, const_cast<double *>(x), false);
+      apply_A_u(c, x, y, mode, nullptr, false, nullptr);
+      la_cons_reduce(c->stream, c->cons_u, y);
+      return false;
+    };
     if (opts->preconditioner == PORO_PREC_FDM) {
       // z = blockdiag(A_cc)^-1 g by fast diagonalisation: the same device-controlled SolverCG recurrence with an explicit preconditioner vector
       build_fdm_u(c);
@@ -1048,10 +1114,11 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       PORO_HIP(hipStreamSynchronize(c->stream));
       return rc;
     }
-    DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim; dv.inert = c->dir_mask.p;
+    DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim; dv.inert = c->cons_u.inert.p;
     if (c->diag_u_cls.p) { dv.cls = c->diag_u_cls.p; dv.tab = c->diag_u_tab.p; }
     const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dv, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, nullptr, c->pcg_hint_u);
     la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);   // constraints.distribute (:306)
+    la_cons_expand(c->stream, c->cons_u, vec(c, PORO_VEC_U), true);
     PORO_HIP(hipStreamSynchronize(c->stream));
     return rc;
   });
@@ -1068,6 +1135,7 @@ int poro_pres_assemble_residual(poro_ctx *c, double dt, double *l2) {
       else la_csr_residual(s, c->Ap, c->Mp.p, c->Kp.p, c->mat.k_over_mu, c->tmp_p.p, vec(c, PORO_VEC_P), c->src_local.p, R);
     }
     exchange_add(c, R, c->n_p, c->comm.part.plane_p);
+    la_cons_reduce(s, c->cons_p, R);                                              // constraints.condense(residual) (:153)
     la_dot_partials(s, R, R, owned(c, c->n_p, c->comm.part.plane_p), c->partials.p);
     la_reduce_finish(s, c->partials.p, 1, c->red.p, 0);
     allreduce_sum(c, c->red.p, 1);
@@ -1088,6 +1156,7 @@ int poro_pres_assemble_jacobian(poro_ctx *c, double dt) {
     exchange_add(c, c->diag_J.p, c->n_p, c->comm.part.plane_p);
     if (!c->dinv_J.p) c->dinv_J.alloc(c->n_p);
     la_reciprocal(c->stream, c->dinv_J.p, c->diag_J.p, c->n_p);
+    if (c->cons_p.n) la_mask_zero(c->stream, c->dinv_J.p, c->cons_p.inert.p, c->n_p);
     c->ilu_J_valid = false;
     c->jac_dt = dt;
     return 0;
@@ -1098,6 +1167,7 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (c->jac_dt < 0) throw Error("pres_solve before pres_assemble_jacobian");
+    if (c->cons_p.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE) throw Error("meshes with hanging-node constraints: PORO_PREC_JACOBI / NONE only");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       return pcg_ilu0(c, c->Ap, c->Jp.p, c->ilu_J, c->ilu_J_valid, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     }
@@ -1105,9 +1175,11 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;   // uniform box: J is a constant-coefficient stencil
     const double ja = 1. / c->mat.biot_M / c->jac_dt, jk = c->mat.k_over_mu;
     auto apply = [&](const double *x, double *y, double *) {
+      la_cons_expand(c->stream, c->cons_p, const_cast<double *>(x), false);      // condensed Jacobian C^T J C (:168)
       if (stencil) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(c->stream, c->dim, c->box, ja, jk, x, y); }
       else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); }
-      exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
+      exchange_add(c, y, c->n_p, c->comm.part.plane_p);
+      la_cons_reduce(c->stream, c->cons_p, y); return false;
     };
     if (opts->preconditioner == PORO_PREC_FDM) {
       build_fdm_p(c);
@@ -1117,8 +1189,10 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       DiagVec dz; dz.full = c->dinv_J.p; dz.z = c->wz_p.p;
       return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
     }
-    DiagVec dv; dv.full = c->dinv_J.p;
-    return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    DiagVec dv; dv.full = c->dinv_J.p; dv.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
+    const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_DP), true);              // constraints.distribute(solution_update) (:180)
+    return rc;
   });
 }
 
@@ -1133,6 +1207,7 @@ int poro_proj_assemble_matrix(poro_ctx *c) {
     exchange_add(c, c->diag_M.p, c->n_p, c->comm.part.plane_p);
     if (!c->dinv_M.p) c->dinv_M.alloc(c->n_p);
     la_reciprocal(c->stream, c->dinv_M.p, c->diag_M.p, c->n_p);
+    if (c->cons_p.n) la_mask_zero(c->stream, c->dinv_M.p, c->cons_p.inert.p, c->n_p);
     c->projection_matrix_ready = true; return 0;
   });
 }
@@ -1157,7 +1232,7 @@ int poro_proj_assemble_rhs(poro_ctx *c, const int32_t *tensor_components, int32_
           asm_proj_rhs(c->stream, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], vec(c, PORO_VEC_U), n_comp, tensor_components, rhs);
       }
     }
-    for (int k = 0; k < n_comp; ++k) exchange_add(c, rhs[k], c->n_p, c->comm.part.plane_p);
+    for (int k = 0; k < n_comp; ++k) { exchange_add(c, rhs[k], c->n_p, c->comm.part.plane_p); la_cons_reduce(c->stream, c->cons_p, rhs[k]); }   // StrainProjector.h:191-194
     return 0;
   });
 }
@@ -1167,15 +1242,18 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
     PORO_HIP(hipSetDevice(c->device));
     if (!c->projection_matrix_ready) throw Error("proj_solve before proj_assemble_matrix");
     if (entry < 0 || entry >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
+    if (c->cons_p.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE) throw Error("meshes with hanging-node constraints: PORO_PREC_JACOBI / NONE only");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       return pcg_ilu0(c, c->Ap, c->Mp.p, c->ilu_M, c->ilu_M_valid, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     }
     if (opts->preconditioner == PORO_PREC_SSOR) return pcg_ssor(c, c->Ap, c->Mp.p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;
     auto apply = [&](const double *x, double *y, double *) {
+      la_cons_expand(c->stream, c->cons_p, const_cast<double *>(x), false);      // condensed projection matrix (StrainProjector.h:104-105)
       if (stencil) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(c->stream, c->dim, c->box, 1.0, 0.0, x, y); }
       else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); }
-      exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
+      exchange_add(c, y, c->n_p, c->comm.part.plane_p);
+      la_cons_reduce(c->stream, c->cons_p, y); return false;
     };
     if (opts->preconditioner == PORO_PREC_FDM) {
       build_fdm_p(c);
@@ -1185,8 +1263,10 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
       DiagVec dz; dz.full = c->dinv_M.p; dz.z = c->wz_p.p;
       return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
     }
-    DiagVec dv; dv.full = c->dinv_M.p;
-    return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    DiagVec dv; dv.full = c->dinv_M.p; dv.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
+    const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_STRAIN0 + entry), true);   // constraints.distribute (StrainProjector.h:216)
+    return rc;
   });
 }
 

@@ -151,6 +151,26 @@ __global__ void k_reciprocal(double *y, const double *x, int64_t n) {
 __global__ void k_pointwise_mul(double *y, const double *x, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] *= x[i];
 }
+__global__ void k_cons_expand(int64_t n, const int32_t *__restrict__ dof, const int64_t *__restrict__ ptr, const int32_t *__restrict__ master, const double *__restrict__ w,
+                              const double *__restrict__ inhom, double *x) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double s = inhom ? inhom[i] : 0.0;
+  for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) s += w[k] * x[master[k]];     // masters are unconstrained: no read-after-write inside the launch
+  x[dof[i]] = s;
+}
+__global__ void k_cons_gather(int64_t n_masters, const int32_t *__restrict__ t_master, const int64_t *__restrict__ t_ptr, const int32_t *__restrict__ t_dof,
+                              const double *__restrict__ t_w, double *y) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_masters) return;
+  double s = 0;
+  for (int64_t k = t_ptr[i]; k < t_ptr[i + 1]; ++k) s += t_w[k] * y[t_dof[k]];
+  y[t_master[i]] += s;
+}
+__global__ void k_cons_zero(int64_t n, const int32_t *__restrict__ dof, double *y) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) y[dof[i]] = 0.0;
+}
 __global__ void k_csr_diag(int64_t n, const int64_t *pos, const double *val, double *diag) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) diag[i] = val[pos[i]];
 }
@@ -428,6 +448,14 @@ void la_ilu_apply(hipStream_t s, const CsrDev &A, const double *lu, const SsorLe
 }
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_reciprocal, grid_for(n), kBlock, 0, s, y, x, n); }
 void la_pointwise_mul(hipStream_t s, double *y, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_pointwise_mul, grid_for(n), kBlock, 0, s, y, x, n); }
+void la_cons_expand(hipStream_t s, const ConsDev &C, double *x, bool with_inhom) {
+  if (C.n) hipLaunchKernelGGL(k_cons_expand, (unsigned)((C.n + kBlock - 1) / kBlock), kBlock, 0, s, C.n, C.dof.p, C.ptr.p, C.master.p, C.weight.p, with_inhom ? C.inhom.p : (const double *)nullptr, x);
+}
+void la_cons_reduce(hipStream_t s, const ConsDev &C, double *y) {
+  if (!C.n) return;
+  if (C.n_masters) hipLaunchKernelGGL(k_cons_gather, (unsigned)((C.n_masters + kBlock - 1) / kBlock), kBlock, 0, s, C.n_masters, C.t_master.p, C.t_ptr.p, C.t_dof.p, C.t_weight.p, y);
+  hipLaunchKernelGGL(k_cons_zero, (unsigned)((C.n + kBlock - 1) / kBlock), kBlock, 0, s, C.n, C.dof.p, y);
+}
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag) {
   hipLaunchKernelGGL(k_csr_diag, grid_for(A.n), kBlock, 0, s, A.n, A.diag_pos.p, val, diag);
 }

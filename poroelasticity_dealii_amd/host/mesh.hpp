@@ -7,6 +7,8 @@
 // Produces the flat arrays of include/poroel_hip.h.
 #pragma once
 #include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdint>
 #include <fstream>
 #include <map>
@@ -209,17 +211,140 @@ inline void make_dirichlet(const Mesh &m, const DoFs &D, const BoundaryCondition
   for (auto &kv : cons) { dofs.push_back(kv.first); values.push_back(kv.second); }
 }
 
+// ---- locally refined box: hanging nodes ---------------------------------------------------------------------------------------------
+// x[dof] = sum w x[master] + inhomogeneity, closed (ConstraintMatrix::close()): masters are unconstrained
+struct ConstraintList {
+  std::vector<int32_t> dof, master; std::vector<int64_t> ptr{0}; std::vector<double> weight, inhom;
+  int64_t n() const { return (int64_t)dof.size(); }
+  poro_constraints c_view() const { return poro_constraints{n(), dof.data(), ptr.data(), master.data(), weight.data(), inhom.data()}; }
+};
+
+// Box of n[d] coarse cells; the coarse cells with index lo[d] <= i_d < hi[d] are replaced by their 2^dim children (one refinement level,
+// the 2:1 situation deal.II allows).  Nodes live on an integer lattice of spacing h / (2 k) per direction, so shared nodes are found by
+// their lattice coordinates.  A node of a fine cell that lies in the closure of an UNREFINED coarse cell without being one of its nodes
+// is a hanging node, constrained by that cell's shape functions evaluated there (what DoFTools::make_hanging_node_constraints builds
+// from the face interpolation matrices of FE_Q).
+struct RefinedBox {
+  Mesh mesh; DoFs dofs; ConstraintList cons_u, cons_p;
+};
+inline RefinedBox make_refined_box(int dim, const int n[3], const double origin[3], const double h[3], int k_u, const int lo[3], const int hi[3]) {
+  RefinedBox R; Mesh &m = R.mesh; m.dim = dim;
+  const int nc[3] = {n[0], n[1], dim == 3 ? n[2] : 1};
+  auto refined = [&](const int c[3]) { for (int d = 0; d < dim; ++d) if (c[d] < lo[d] || c[d] >= hi[d]) return false; return true; };
+  struct Cell { int c[3]; int child[3]; bool fine; };
+  std::vector<Cell> cells;
+  for (int k = 0; k < nc[2]; ++k) for (int j = 0; j < nc[1]; ++j) for (int i = 0; i < nc[0]; ++i) {
+    const int c[3] = {i, j, k};
+    if (!refined(c)) { cells.push_back(Cell{{i, j, k}, {0, 0, 0}, false}); continue; }
+    for (int cz = 0; cz < (dim == 3 ? 2 : 1); ++cz) for (int cy = 0; cy < 2; ++cy) for (int cx = 0; cx < 2; ++cx) cells.push_back(Cell{{i, j, k}, {cx, cy, cz}, true});
+  }
+  // lattice numbering of one scalar space of degree k: key = lattice coordinates in units h / (2k)
+  auto key_of = [&](int k, const int X[3]) { const int64_t L1 = 2 * k * nc[0] + 1, L2 = 2 * k * nc[1] + 1; return ((int64_t)(dim == 3 ? X[2] : 0) * L2 + X[1]) * L1 + X[0]; };
+  auto number_space = [&](int k, std::vector<int32_t> &cell_nodes, std::map<int64_t, int32_t> &id, std::vector<std::array<int, 3>> &coord) {
+    const int n1 = k + 1, ns = ipow(n1, dim);
+    cell_nodes.assign(cells.size() * ns, -1);
+    for (size_t ci = 0; ci < cells.size(); ++ci) for (int s = 0; s < ns; ++s) {
+      const Cell &C = cells[ci]; const int a[3] = {s % n1, (s / n1) % n1, s / (n1 * n1)}; int X[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) X[d] = 2 * k * C.c[d] + (C.fine ? k * C.child[d] + a[d] : 2 * a[d]);
+      const int64_t key = key_of(k, X);
+      auto it = id.find(key);
+      if (it == id.end()) { it = id.emplace(key, (int32_t)coord.size()).first; coord.push_back({X[0], X[1], X[2]}); }
+      cell_nodes[ci * ns + s] = it->second;
+    }
+  };
+  // hanging nodes of one scalar space: list of (node, masters, weights)
+  auto hanging = [&](int k, const std::map<int64_t, int32_t> &id, const std::vector<std::array<int, 3>> &coord, std::vector<int32_t> &hn, std::vector<std::vector<std::pair<int32_t, double>>> &hw) {
+    const int n1 = k + 1, ns = ipow(n1, dim);
+    for (size_t nd = 0; nd < coord.size(); ++nd) {
+      const int *X = coord[nd].data();
+      bool odd = false; for (int d = 0; d < dim; ++d) odd = odd || (X[d] & 1);
+      if (!odd) continue;                                    // a node of the coarse lattice can never hang
+      // unrefined coarse cells whose closure contains X
+      int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) { const int q = X[d] / (2 * k), r = X[d] % (2 * k); c1[d] = std::min(q, nc[d] - 1); c0[d] = (r == 0 && q > 0) ? q - 1 : c1[d]; }
+      bool done = false;
+      for (int ck = c0[2]; ck <= c1[2] && !done; ++ck) for (int cj = c0[1]; cj <= c1[1] && !done; ++cj) for (int ci = c0[0]; ci <= c1[0] && !done; ++ci) {
+        const int c[3] = {ci, cj, ck};
+        if (refined(c)) continue;
+        double xi[3] = {0, 0, 0}; for (int d = 0; d < dim; ++d) xi[d] = (double)(X[d] - 2 * k * c[d]) / (2 * k);
+        std::vector<double> val(ns), grad((size_t)ns * dim); shape_at(dim, k, xi, val.data(), grad.data());
+        std::vector<std::pair<int32_t, double>> w;
+        for (int s = 0; s < ns; ++s) if (std::fabs(val[s]) > 1e-13) {
+          const int a[3] = {s % n1, (s / n1) % n1, s / (n1 * n1)}; int Y[3] = {0, 0, 0};
+          for (int d = 0; d < dim; ++d) Y[d] = 2 * k * c[d] + 2 * a[d];
+          w.emplace_back(id.at(key_of(k, Y)), val[s]);
+        }
+        hn.push_back((int32_t)nd); hw.push_back(w); done = true;
+      }
+    }
+  };
+  // pressure space = vertices (k = 1)
+  std::map<int64_t, int32_t> idp, idu; std::vector<std::array<int, 3>> cp, cu; std::vector<int32_t> nodes_p, nodes_u;
+  number_space(1, nodes_p, idp, cp);
+  number_space(k_u, nodes_u, idu, cu);
+  m.vertices.resize(cp.size() * dim);
+  for (size_t v = 0; v < cp.size(); ++v) for (int d = 0; d < dim; ++d) m.vertices[v * dim + d] = origin[d] + 0.5 * h[d] * cp[v][d];
+  m.cells = nodes_p;
+  const int nvc = 1 << dim;
+  for (size_t ci = 0; ci < cells.size(); ++ci) for (int d = 0; d < dim; ++d) for (int side = 0; side < 2; ++side) {
+    const Cell &C = cells[ci];
+    const bool at = side ? (C.c[d] == nc[d] - 1 && (!C.fine || C.child[d] == 1)) : (C.c[d] == 0 && (!C.fine || C.child[d] == 0));
+    if (at) { m.bface_cell.push_back((int32_t)ci); m.bface_local.push_back(2 * d + side); m.bface_id.push_back(2 * d + side); }
+  }
+  (void)nvc;
+  DoFs &D = R.dofs; D.k_u = k_u; D.n_p = (int64_t)cp.size(); D.n_u = (int64_t)cu.size() * dim; D.cell_p = nodes_p;
+  D.cell_u.resize(nodes_u.size() * dim);
+  for (size_t i = 0; i < nodes_u.size(); ++i) for (int d = 0; d < dim; ++d) D.cell_u[i * dim + d] = nodes_u[i] * dim + d;
+  std::vector<int32_t> hn; std::vector<std::vector<std::pair<int32_t, double>>> hw;
+  hanging(1, idp, cp, hn, hw);
+  for (size_t i = 0; i < hn.size(); ++i) {
+    R.cons_p.dof.push_back(hn[i]); R.cons_p.inhom.push_back(0.0);
+    for (auto &mw : hw[i]) { R.cons_p.master.push_back(mw.first); R.cons_p.weight.push_back(mw.second); }
+    R.cons_p.ptr.push_back((int64_t)R.cons_p.master.size());
+  }
+  hn.clear(); hw.clear();
+  hanging(k_u, idu, cu, hn, hw);
+  for (size_t i = 0; i < hn.size(); ++i) for (int d = 0; d < dim; ++d) {
+    R.cons_u.dof.push_back(hn[i] * dim + d); R.cons_u.inhom.push_back(0.0);
+    for (auto &mw : hw[i]) { R.cons_u.master.push_back(mw.first * dim + d); R.cons_u.weight.push_back(mw.second); }
+    R.cons_u.ptr.push_back((int64_t)R.cons_u.master.size());
+  }
+  return R;
+}
+
 // Everything poro_desc points at, owned in one place.
 struct ProblemData {
   Mesh mesh; DoFs dofs; FETables fe; BoundaryConditions bc;
   std::vector<int32_t> dirichlet_dof; std::vector<double> dirichlet_value;
   poro_material mat{}; poro_partition part{};
+  ConstraintList cons_u, cons_p;      // hanging-node constraints (locally refined meshes)
   poro_desc d{};
 
-  void finalize(int k_u) {
-    dofs = distribute_dofs(mesh, k_u);
+  // ConstraintMatrix semantics of PoroElasticDisplacementSolver.h:112-136: hanging-node constraints first, boundary values only for dofs that are
+  // not constrained yet, then close(): a hanging node whose master carries a boundary value gets it as an inhomogeneity
+  void close_constraints() {
+    if (!cons_u.n()) return;
+    std::map<int32_t, double> dir; for (size_t i = 0; i < dirichlet_dof.size(); ++i) dir[dirichlet_dof[i]] = dirichlet_value[i];
+    for (int32_t hd : cons_u.dof) dir.erase(hd);
+    ConstraintList out;
+    for (int64_t i = 0; i < cons_u.n(); ++i) {
+      double b = cons_u.inhom[i];
+      out.dof.push_back(cons_u.dof[i]);
+      for (int64_t k = cons_u.ptr[i]; k < cons_u.ptr[i + 1]; ++k) {
+        auto it = dir.find(cons_u.master[k]);
+        if (it != dir.end()) b += cons_u.weight[k] * it->second; else { out.master.push_back(cons_u.master[k]); out.weight.push_back(cons_u.weight[k]); }
+      }
+      out.inhom.push_back(b); out.ptr.push_back((int64_t)out.master.size());
+    }
+    cons_u = out;
+    dirichlet_dof.clear(); dirichlet_value.clear();
+    for (auto &kv : dir) { dirichlet_dof.push_back(kv.first); dirichlet_value.push_back(kv.second); }
+  }
+  void finalize(int k_u, bool have_dofs = false) {
+    if (!have_dofs) dofs = distribute_dofs(mesh, k_u);
     fe.build(mesh.dim, k_u);
     make_dirichlet(mesh, dofs, bc, dirichlet_dof, dirichlet_value);
+    close_constraints();
     d = poro_desc{};
     d.abi_version = PORO_ABI_VERSION; d.dim = mesh.dim; d.degree_u = k_u; d.degree_p = 1;
     d.n_cells = mesh.n_cells(); d.n_vertices = mesh.n_vertices(); d.n_dofs_u = dofs.n_u; d.n_dofs_p = dofs.n_p;
@@ -234,6 +359,7 @@ struct ProblemData {
     d.mat = mat; d.box = mesh.box;
     if (part.n_ranks == 0) { part.n_ranks = 1; part.rank = 0; }
     d.part = part;
+    d.cons_u = cons_u.c_view(); d.cons_p = cons_p.c_view();
   }
 };
 
@@ -261,6 +387,15 @@ inline void build_box_problem(ProblemData &P, int dim, const int n[3], const dou
   for (int d = 0; d < sd; ++d) { pu *= (k_u * n[d] + 1); pp *= (n[d] + 1); }
   P.part.plane_u = pu; P.part.plane_p = pp;
   P.finalize(k_u);
+}
+
+inline void build_refined_box_problem(ProblemData &P, int dim, const int n[3], const double size[3], int k_u, const int lo[3], const int hi[3]) {
+  double origin[3] = {0, 0, 0}, h[3] = {1, 1, 1};
+  for (int d = 0; d < dim; ++d) { h[d] = size[d] / n[d]; origin[d] = -size[d] / 2; }
+  RefinedBox R = make_refined_box(dim, n, origin, h, k_u, lo, hi);
+  P.mesh = std::move(R.mesh); P.dofs = std::move(R.dofs); P.cons_u = std::move(R.cons_u); P.cons_p = std::move(R.cons_p);
+  P.part = poro_partition{}; P.part.n_ranks = 1;
+  P.finalize(k_u, true);
 }
 
 }  // namespace poro_host
