@@ -110,12 +110,12 @@ def kernel_source_stamp():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def committed_traffic(dim, deg, n):
+def committed_traffic(dim, deg, n, fused_cheb=False):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     tools/bench_ops.py on this workload, gfx950 x2 read correction; tools/pmc_summary.py).  The file carries the stamp of the kernel source it was
     measured on; a different source (or no file) gives null rather than a stale number."""
     try:
-        key = {(2, 72): "poro::k_kron3_q2", (1, 99): "poro::k_kron3_q1"}[(deg, n)] if dim == 3 else None
+        key = {(2, 72): "poro::k_kron3_q2", (1, 99): "poro::k_kron3_q1"}[(deg, n)] + ("_cheb" if fused_cheb else "") if dim == 3 else None
         with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             rec = json.load(f)
         if rec.get("kernel_source_sha16") != kernel_source_stamp():
@@ -133,7 +133,7 @@ def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist,
         n[dim - 1] = args.n * world; size[dim - 1] = 10.0 * world
     P = pk.Problem.box(dim, n, size, deg, material(), BC_3D[:2 * dim], (), rank, world)
     R = pk.Runner(P, device=local_rank, operator_mode=pk.OP_MATRIX_FREE, p_init=INPUT["p_init"], dt=INPUT["dt"], abs_u=1e-12, rel_u=args.rel_tol, max_it=args.max_iter,
-                  prec=pk.PREC_JACOBI if prec is None else prec, reduction=args.stop == "reduction")
+                  prec=pk.PREC_JACOBI if prec is None else prec, reduction=args.stop == "reduction", cheb_degree=args.cheb_degree)
     G = R.ctx
     if world > 1 and args.share_gpu:
         import numpy as np
@@ -191,8 +191,8 @@ def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist,
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt[0])
     work = {k: after[k] - before[k] for k in after}
-    families = ("apply_u_matrix_free", "apply_u_dirichlet_rows", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr", "apply_p_stencil",
-                "precondition_p_fdm", "precondition_u_fdm", "halo_exchange", "allreduce", "alltoall")
+    families = ("apply_u_matrix_free", "apply_u_chebyshev_fused", "apply_u_dirichlet_rows", "assemble_u_rhs", "projection_rhs", "pressure_residual", "pressure_jacobian", "apply_p_csr", "apply_p_stencil",
+                "precondition_p_fdm", "precondition_u_fdm", "precondition_u_chebyshev", "halo_exchange", "allreduce", "alltoall")
     out = {"n": n, "n_u_glob": n_u_glob, "n_p_glob": n_p_glob, "n_u_local": P.desc.n_dofs_u, "n_cells_local": n_cells, "elapsed": elapsed, "work": work,
            "updates": dof_updates(work, n_u_glob, n_p_glob, dim), "traces": traces, "step_seconds": step_seconds,
            "kernel_time": {k: G.timer(k) for k in families}}
@@ -217,6 +217,10 @@ def main():
     ap.add_argument("--transient", action="store_true",
                     help="time consecutive steps of the transient (BASELINE config 5) instead of repeating time step 1: the steps then differ (the input.data well rate is tiny, "
                          "the transient dies within ~10 steps) and ms_per_step depends on the window")
+    ap.add_argument("--prec", choices=["chebyshev", "jacobi"], default="chebyshev",
+                    help="preconditioner of the displacement CG in the headline run: chebyshev = Chebyshev polynomial around Jacobi, on 3D boxes fused into the operator kernel "
+                         "(the other one and the block fast diagonalisation are measured as well and reported under time_to_solution)")
+    ap.add_argument("--cheb-degree", type=int, default=4)
     ap.add_argument("--max-iter", type=int, default=50000)
     ap.add_argument("--cpu-n", type=int, default=9, help="cells per direction of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -244,46 +248,65 @@ def main():
         torch = None
 
     dim, deg = args.dim, args.degree
-    fdm_variant = not args.no_variants
+    PREC = {"jacobi": pk.PREC_JACOBI, "chebyshev": pk.PREC_CHEBYSHEV, "block_fdm": pk.PREC_FDM}
+    head = args.prec
+    others = [] if args.no_variants else [k for k in ("jacobi", "chebyshev", "block_fdm") if k != head]
     weak_line = world > 1 and args.scaling == "strong" and not args.no_weak_line
     rccl_ids = {}
     if world > 1 and not args.share_gpu:      # one communicator per context that will be created, ids from rank 0
-        labels = ["jacobi" + args.scaling] + (["fdm" + args.scaling] if fdm_variant else []) + (["jacobiweak"] if weak_line else [])
+        labels = [head + args.scaling] + [k + args.scaling for k in others] + ([head + "weak"] if weak_line else [])
         ids = [{lb: pk.rccl_unique_id() for lb in labels} if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         rccl_ids = ids[0]
 
-    M = run_case(args, args.scaling, args.steps, args.warmup, rank, world, local_rank, torch, dist, rccl_ids)
+    M = run_case(args, args.scaling, args.steps, args.warmup, rank, world, local_rank, torch, dist, rccl_ids, prec=PREC[head], label=head)
     work, elapsed, updates, traces, step_seconds = M["work"], M["elapsed"], M["updates"], M["traces"], M["step_seconds"]
     n, n_u_glob, n_p_glob = M["n"], M["n_u_glob"], M["n_p_glob"]
     kernel_time = M["kernel_time"]
 
-    # roofline of the dominant kernel: the matrix-free A_u application (per launch, per GPU)
-    # launches enqueued behind the finishing iteration of a solve return at once (no-ops, ~2 us): their time stays in the numerator, but the
-    # average is taken over the useful applications only (conservative by ~0.2 %)
-    t_apply, n_launched = kernel_time["apply_u_matrix_free"]
-    n_apply = int(work["apply_u"]) or n_launched
+    # roofline of the dominant kernel (per launch, per GPU).  Chebyshev-CG on a 3D box: the structured operator with the polynomial recurrence fused into
+    # its stores (k_kron3_*_cheb: reads z_j, g, z_{j-1}, writes z_{j+1} = 32 B / DoF, + the 8d element-index bytes the structured kernels do not read);
+    # otherwise the plain operator y = A_u x (16 B / DoF + index bytes).  Launches enqueued behind the finishing iteration of a solve return at once
+    # (no-ops, ~2 us): their time stays in the numerator, the average is taken over the useful applications only.
+    t_plain, n_plain_launched = kernel_time["apply_u_matrix_free"]
+    t_cheb, n_cheb_launched = kernel_time["apply_u_chebyshev_fused"]
+    alg_plain = bytes_per_apply(dim, deg, M["n_u_local"], M["n_cells_local"], "matrix_free")
+    cg_total = int(work["cg_u"]); solves = int(work["asm_rhs_u"])
+    fused_cheb = n_cheb_launched > 0
+    if fused_cheb:
+        n_cheb_useful = args.cheb_degree * (cg_total + solves) if args.cheb_degree % 2 == 0 else (args.cheb_degree + 1) * (cg_total + solves)
+        n_plain_useful = cg_total + solves
+        n_apply, t_apply, n_launched = n_cheb_useful, t_cheb, n_cheb_launched
+        alg_bytes = alg_plain + 16.0 * M["n_u_local"]
+        kernel_label = "k_kron3_q%d_cheb (matrix-free A_u z_j with the Chebyshev update z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 D^-1 (g - A z_j) fused into the stores)" % deg
+    else:
+        n_apply = int(work["apply_u"]) or n_plain_launched
+        n_plain_useful = n_apply; t_apply, n_launched = t_plain, n_plain_launched
+        alg_bytes = alg_plain
+        kernel_label = ("k_kron3_q%d" % deg if dim == 3 else "k_kron2<%d>" % deg) + " (matrix-free y = A_u x, sum-factorised)"
     avg_apply = t_apply / max(n_apply, 1)
-    alg_bytes = bytes_per_apply(dim, deg, M["n_u_local"], M["n_cells_local"], "matrix_free")
     achieved = alg_bytes / avg_apply / 1e9 if n_apply else 0.0
+    avg_plain = t_plain / max(n_plain_useful, 1)
     t_fix, n_fix = kernel_time["apply_u_dirichlet_rows"]
-    kernel_label = ("k_kron3_q%d" % deg if dim == 3 else "k_kron2<%d>" % deg) + " (matrix-free y = A_u x, sum-factorised)"
-    traffic = committed_traffic(dim, deg, args.n) if world == 1 else None
+    traffic = committed_traffic(dim, deg, args.n, fused_cheb) if world == 1 else None
 
-    # time-to-solution variant: the same steps with the block fast-diagonalisation preconditioner of the displacement system
-    variant = None
-    if fdm_variant:
+    # the same steps with the other preconditioners of the displacement CG (time to solution; the headline is the run above)
+    def summary(V, prec_name):
+        d = {"ms_per_step": 1e3 * V["elapsed"] / args.steps, "cg_iterations_u": [[int(r[6]) for r in t] for t in V["traces"]],
+             "operator_applications_per_step": V["work"]["apply_u"] / args.steps, "DoF_updates_per_s": V["updates"] / V["elapsed"]}
+        if prec_name == "block_fdm":
+            d.update({"seconds_precondition_u": V["kernel_time"]["precondition_u_fdm"][0], "applications_precondition_u": V["kernel_time"]["precondition_u_fdm"][1],
+                      "seconds_alltoall": V["kernel_time"]["alltoall"][0]})
+        return d
+    tts = {head: summary(M, head)}
+    for k in others:
         try:
-            V = run_case(args, args.scaling, args.steps, args.warmup, rank, world, local_rank, torch, dist, rccl_ids, prec=pk.PREC_FDM, label="fdm")
-            variant = {"preconditioner_u": "block fast diagonalisation (PORO_PREC_FDM)", "ms_per_step": 1e3 * V["elapsed"] / args.steps,
-                       "cg_iterations_u": [[int(r[6]) for r in t] for t in V["traces"]], "DoF_updates_per_s": V["updates"] / V["elapsed"],
-                       "seconds_precondition_u": V["kernel_time"]["precondition_u_fdm"][0], "applications_precondition_u": V["kernel_time"]["precondition_u_fdm"][1],
-                       "seconds_alltoall": V["kernel_time"]["alltoall"][0]}
+            tts[k] = summary(run_case(args, args.scaling, args.steps, args.warmup, rank, world, local_rank, torch, dist, rccl_ids, prec=PREC[k], label=k), k)
         except RuntimeError as exc:           # a context that cannot use it (e.g. Dirichlet data not face-separable) says so; the headline stays valid
-            variant = {"error": str(exc)}
+            tts[k] = {"error": str(exc)}
     weak = None
     if weak_line:
-        W = run_case(args, "weak", min(args.steps, 3), 1, rank, world, local_rank, torch, dist, rccl_ids, label="jacobi")
+        W = run_case(args, "weak", min(args.steps, 3), 1, rank, world, local_rank, torch, dist, rccl_ids, prec=PREC[head], label=head)
         weak = {"value": W["updates"] / W["elapsed"], "ms_per_step": 1e3 * W["elapsed"] / min(args.steps, 3), "cells": "x".join(map(str, W["n"])), "N_u": W["n_u_glob"],
                 "cg_iterations_u": [[int(r[6]) for r in t] for t in W["traces"]]}
 
@@ -297,24 +320,27 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{dim}D Q{deg}/Q1 uniform box, {'x'.join(map(str, n))} cells, N_u={n_u_glob}, N_p={n_p_glob}; {'consecutive time steps' if args.transient else 'time step 1 repeated (device-side rollback before each step)'}; one time step = one fixed-stress iteration "
-                                   f"(pressure loop + matrix-free Jacobi-PCG displacement solve + strain projection); input.data material/BCs, z-face BCs per SURVEY Q9",
+                                   f"(pressure loop + matrix-free PCG displacement solve, preconditioner: {head}" + (f" degree {args.cheb_degree}" if head == "chebyshev" else "") + " + strain projection); input.data material/BCs, z-face BCs per SURVEY Q9",
                        "parallelism": f"z-slab x{world}" if world > 1 else "single GPU", "operator": "matrix_free",
                        "stopping_rule_u": stop_txt},
             "cg_iterations_u": cg_u,
             "roofline": {"bound": "hbm", "kernel": kernel_label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e6 * avg_apply, "launches_timed": n_apply, "launches_enqueued": n_launched,
-                         "note": ("operator kernel alone (as rocprofv3 reports it); inside PCG the Dirichlet dofs are inert (zero residual / direction), so no row fix-up runs "
+                         "frac_without_index_bytes": (alg_bytes - 4.0 * dim * (deg + 1) ** dim * M["n_cells_local"]) / avg_apply / 1e9 / HBM_PEAK_GBS if n_apply else 0.0,
+                         "plain_operator": {"kernel": ("k_kron3_q%d" % deg if dim == 3 else "k_kron2<%d>" % deg), "avg_launch_us": 1e6 * avg_plain, "algorithmic_bytes_per_launch": alg_plain,
+                                            "achieved": alg_plain / avg_plain / 1e9 if n_plain_useful and t_plain else 0.0, "frac": alg_plain / avg_plain / 1e9 / HBM_PEAK_GBS if n_plain_useful and t_plain else 0.0},
+                         "note": ("kernel alone (HIP events attached to the dispatch, as rocprofv3 reports it); inside PCG the Dirichlet dofs are inert (zero residual / direction), so no row fix-up runs "
                                   "(k_kron_fix_constrained only serves poro_apply_operator: %d launches in the timed region); "
-                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells) although the structured kernels read no index arrays; "
+                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells per operator application, + 16 N for the two extra streams of the fused Chebyshev update) although the "
+                                  "structured kernels read no index arrays (frac_without_index_bytes leaves them out); "
                                   "traffic = PMC bytes per launch from profiles/r02_pmc_traffic.json, null unless that file was measured on this kernel source") % n_fix},
             "work_per_step": {k: work[k] / args.steps for k in work},
-            "kernel_only": {"apply_u_DoF_updates_per_s": (M["n_u_local"] / (avg_apply + t_fix / max(n_fix, 1))) if n_apply else 0.0,
+            "kernel_only": {"apply_u_DoF_updates_per_s": (M["n_u_local"] / (avg_plain + t_fix / max(n_fix, 1))) if n_plain_useful and t_plain else 0.0,
                             "seconds_by_family": {k: v[0] for k, v in kernel_time.items()}, "launches_by_family": {k: v[1] for k, v in kernel_time.items()}},
             "fss_iterations_per_step": [int(len(t)) for t in traces],
         }
-        if variant is not None:
-            out["time_to_solution"] = {"jacobi_ms_per_step": out["ms_per_step"], "block_fdm": variant}
+        out["time_to_solution"] = tts
         if weak is not None:
             out["weak_scaling_line"] = weak
         if world == 1 and not args.no_cpu_baseline:

@@ -155,7 +155,8 @@ typedef struct poro_solver_opts {
   int32_t preconditioner;  /* PORO_PREC_* */
   double  omega;           /* relaxation of PORO_PREC_SSOR: 1.2 displacement (:303), 1.0 pressure / projection (:178, StrainProjector.h:212) */
   int32_t stop_rule;       /* PORO_STOP_* */
-  int32_t reserved_;
+  int32_t poly_degree;     /* PORO_PREC_CHEBYSHEV: operator applications per preconditioner call (<= 0: 4); `omega` then holds the ratio lambda_max / a of
+                              the interval [a, lambda_max] the polynomial is built for (<= 0: a mesh-size based default) */
 } poro_solver_opts;
 enum { PORO_STOP_RHS = 0, PORO_STOP_REDUCTION = 1 };
 
@@ -168,8 +169,12 @@ enum { PORO_STOP_RHS = 0, PORO_STOP_REDUCTION = 1 };
  * displacement component) are Kronecker sums of 1D FE_Q(k) matrices whenever every Dirichlet condition covers whole faces, and are inverted
  * exactly the same way (per-component 1D eigenvectors, fp64 MFMA transforms); CG on a 10 M-dof box then takes ~20 iterations instead of ~250.
  * PORO_PREC_ILU0 = incomplete LU on the pattern of the assembled CSR matrix (factorised on the host once per matrix, level-scheduled
- * triangular solves on the device; one rank, moderate sizes). */
-enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3, PORO_PREC_ILU0 = 4 };
+ * triangular solves on the device; one rank, moderate sizes).
+ * PORO_PREC_CHEBYSHEV (displacement system) = Chebyshev polynomial in D^-1 A of degree poly_degree around the Jacobi preconditioner: the CG iteration
+ * count drops by about the degree + 1 while the operator applications of the polynomial need no dot products and, on 3D boxes, no vector kernels either
+ * (the recurrence is applied inside the structured operator kernel where the product leaves the registers): fewer bytes and far fewer reductions per
+ * operator application than Jacobi-CG.  lambda_max(D^-1 A) is estimated by a power iteration when the matrix is (re)built. */
+enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3, PORO_PREC_ILU0 = 4, PORO_PREC_CHEBYSHEV = 5 };
 enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };
 enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_JACOBIAN_P = 3 };
 enum { PORO_VEC_U = 0, PORO_VEC_RHS_U = 1, PORO_VEC_P = 2, PORO_VEC_P_OLD = 3, PORO_VEC_DP = 4,

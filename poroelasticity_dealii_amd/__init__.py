@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 # ids of include/poroel_hip.h
-PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM, PREC_ILU0 = 0, 1, 2, 3, 4
+PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM, PREC_ILU0, PREC_CHEBYSHEV = 0, 1, 2, 3, 4, 5
 STOP_RHS, STOP_REDUCTION = 0, 1
 OP_CSR, OP_MATRIX_FREE = 0, 1
 MAT_A_U, MAT_MASS_P, MAT_LAPLACE_P, MAT_JACOBIAN_P = 0, 1, 2, 3
@@ -59,7 +59,7 @@ class Desc(C.Structure):
 
 class SolverOpts(C.Structure):
     _fields_ = [("abs_tol", C.c_double), ("rel_tol", C.c_double), ("max_iter", C.c_int32), ("preconditioner", C.c_int32), ("omega", C.c_double),
-                ("stop_rule", C.c_int32), ("reserved_", C.c_int32)]
+                ("stop_rule", C.c_int32), ("poly_degree", C.c_int32)]
 
 
 class SolveInfo(C.Structure):
@@ -311,16 +311,19 @@ class Context:
         self._chk(self.L.poro_disp_assemble_system(self.ptr, int(rebuild)))
 
     @staticmethod
-    def _opts(abs_tol, rel_tol, max_iter, prec, omega=1.0, stop_rule=STOP_RHS):
-        return SolverOpts(abs_tol, rel_tol, max_iter, prec, omega, stop_rule, 0)
+    def _opts(abs_tol, rel_tol, max_iter, prec, omega=1.0, stop_rule=STOP_RHS, poly_degree=0):
+        return SolverOpts(abs_tol, rel_tol, max_iter, prec, omega, stop_rule, poly_degree)
 
     def supports_preconditioner(self, which_system, prec):
         """which_system: 0 displacement, 1 pressure / projection."""
         return bool(self.L.poro_supports_preconditioner(self.ptr, which_system, prec))
 
-    def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_JACOBI, omega=1.2, reduction=False):
+    def disp_solve(self, abs_tol=1e-12, rel_tol=0.0, max_iter=1000, prec=PREC_JACOBI, omega=1.2, reduction=False, poly_degree=0):
+        """omega: SSOR relaxation, or (PREC_CHEBYSHEV) the interval ratio lambda_max / a (<= 0: default); poly_degree: Chebyshev degree (0: default)"""
         info = SolveInfo()
-        rc = self._chk(self.L.poro_disp_solve(self.ptr, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega, STOP_REDUCTION if reduction else STOP_RHS)), C.byref(info)))
+        if prec == PREC_CHEBYSHEV and omega == 1.2:
+            omega = 0.0
+        rc = self._chk(self.L.poro_disp_solve(self.ptr, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega, STOP_REDUCTION if reduction else STOP_RHS, poly_degree)), C.byref(info)))
         return rc, info
 
     def pres_assemble_residual(self, dt):
@@ -418,13 +421,13 @@ def rccl_unique_id():
 
 
 def run_problem(problem, n_steps, p_init, dt, device=0, operator_mode=OP_CSR, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
-                abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False):
+                abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False, cheb_degree=0, cheb_ratio=0):
     """PoroElasticProblem<dim>::run() (PoroelasticityFSS.h:294-415) through the C++ host driver; returns (trace, Context)."""
     H = load_host()
     max_rows = 1 + n_steps * max_fss
     trace = np.zeros((max_rows, 8))
     ctx = C.c_void_p()
-    rows = H.poro_host_run(problem.handle, device, operator_mode, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0),
+    rows = H.poro_host_run(problem.handle, device, operator_mode, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0) | (int(cheb_degree) << 8) | (int(cheb_ratio) << 16),
                            trace.ctypes.data_as(_dp), max_rows, C.byref(ctx))
     if rows < 0:
         raise RuntimeError(H.poro_host_last_error().decode())
@@ -438,10 +441,10 @@ class Runner:
     """Steppable PoroElasticProblem<dim> (C++ host driver): initialize() = PoroelasticityFSS.h:308-317, step() = one pass of :328-407."""
 
     def __init__(self, problem, device=0, operator_mode=OP_MATRIX_FREE, p_init=10e6, dt=60.0, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
-                 abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False):
+                 abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False, cheb_degree=0, cheb_ratio=0):
         self.H = load_host()
         self.max_fss = max_fss
-        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0))
+        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0) | (int(cheb_degree) << 8) | (int(cheb_ratio) << 16))
         if not h:
             raise RuntimeError(self.H.poro_host_last_error().decode())
         self.h = C.c_void_p(h)

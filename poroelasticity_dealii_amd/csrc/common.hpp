@@ -149,12 +149,14 @@ struct poro_ctx {
   poro::DevBuf<double> ilu_u, ilu_J, ilu_M; bool ilu_u_valid = false, ilu_J_valid = false, ilu_M_valid = false;   // ILU(0) factors on the CSR patterns
   poro::DevBuf<double> wz_p;   // z = P^-1 g of an explicit preconditioner (pressure-sized systems)
   poro::FdmScalar fdm_p; poro::FdmDist fdm_dist; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
+  double cheb_lmax = 0;   // estimate of lambda_max(D^-1 A_u) (power iteration at matrix build; 0 = not yet computed)
+  poro::DevBuf<double> cheb_z, cheb_t;
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   bool matrix_built = false;
   int interleaved_u = 0;
-  int pcg_hint_fdm_u[2] = {0, 0};
+  int pcg_hint_fdm_u[2] = {0, 0}, pcg_hint_cheb_u[2] = {0, 0}; int64_t cheb_applies = 0;
   int pcg_hint_u[2] = {0, 0};   // iterations of the last two displacement solves (batch scheduling of the next one)
   int n_cus = 256; int mf_variant = 1 /* 0 element-matrix gather, 1 sum-factorised (where supported) */; int mask_anywhere = 0;
   // timing
@@ -183,6 +185,11 @@ void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, dou
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag);
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n);
 void la_pointwise_mul(hipStream_t s, double *y, const double *x, int64_t n);   // y *= x
+// Chebyshev recurrence around the (inverse) Jacobi diagonal: z1 = s D^-1 g;  z_new = z_j + c1 (z_j - z_prev) + c2 D^-1 (g - A z_j) (z_new may alias z_prev;
+// z_prev == nullptr: zero); gz_partials != nullptr: block partials of g . z_new over the first n_owned entries
+void la_cheb_first(hipStream_t s, double *z, const double *g, const DiagVec &dv, double scale, int64_t n);
+void la_cheb_step(hipStream_t s, double *znew, const double *zj, const double *zprev, const double *g, const double *Az, const DiagVec &dv, double c1, double c2, int64_t n,
+                  int64_t n_owned, double *gz_partials);
 // x[dof_i] = sum_k w_k x[master_k] (+ inhomogeneity_i): ConstraintMatrix::distribute; with_inhom = false inside the Krylov iteration
 void la_cons_expand(hipStream_t s, const ConsDev &C, double *x, bool with_inhom);
 // y <- C^T y: y[master] += sum w y[dof_i], then y[dof_i] = 0 (ConstraintMatrix::condense of a vector)
@@ -234,6 +241,8 @@ void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
 void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double kappa, const double *x, double *y);
 void p_residual_stencil(hipStream_t s, int dim, const BoxDev &box, double kappa, const double *t, const double *p, const double *src, double *R);
 
+// Chebyshev step fused into the structured operator's stores: z_new = z_j + c1 (z_j - z_prev) + c2 D^-1 (g - A z_j), D^-1 in dictionary form
+struct KronCheb { const double *g = nullptr, *zprev = nullptr; double *znew = nullptr; double c1 = 0, c2 = 0; const uint8_t *cls = nullptr; const double *tab = nullptr; int first = 0 /* z_prev = 0 */; };
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);
 void kron_prepare_device();   // per-device function attributes (dynamic LDS opt-in) of the structured kernels; call after hipSetDevice
@@ -246,6 +255,8 @@ void fdm_window(hipStream_t s, double *dst, const double *src, bool to_block, in
 void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t n_outer, const double *in, double *out, const FdmScale *scale);
 void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], const double *g, double *z, double *t1, double *t2);
 // ---- kernels_fdmu.hip ---------------------------------------------------------------------------
+double jacobi_scaled_lambda_max(int n, const std::vector<double> &A);
+double sym_lambda_max(int n, const std::vector<double> &A);   // largest eigenvalue of a small dense symmetric matrix
 void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::vector<double> &S, std::vector<double> &lam);
 void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single);
 // stage 2: the whole application (single rank); 0 / 1: the passes of the leading directions before / after the caller's distributed last direction
@@ -255,7 +266,8 @@ void fdmu_window(hipStream_t s, double *dst, const double *src, bool to_block, i
 void fdmu_lines(hipStream_t s, const FdmU &F, const FdmuDir *last_dir, int64_t C, int64_t col0, int64_t ncol_valid, void *in, void *out);
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
 int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-               const PcgScalars *pcg = nullptr /* launch becomes a no-op once pcg->done / finishing is set */);   // returns the workgroup count (= partial slots used)
+               const PcgScalars *pcg = nullptr /* launch becomes a no-op once pcg->done / finishing is set */,
+               const KronCheb *cheb = nullptr /* 3D only: store the Chebyshev update instead of the product (y is not written) */);   // returns the workgroup count (= partial slots used)
 void kron_fix_constrained(hipStream_t s, const MfArgs &a, const double *x, double *y, double *dot_partials, int slot_base);
 
 }  // namespace poro

@@ -235,10 +235,11 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
 // apply(x, y, dot_partials) as apply_A_u.  The vector kernels compute alpha / beta / the stopping test in their prologues: from the
 // block partials (single rank, 3 launches per iteration incl. the operator) or from the all-reduced scalars (partitioned).
 // precond != null: explicit preconditioner z = P^-1 g (a sequence of launches on the stream, e.g. the fast diagonalisation) written into
-// diag.z between the two update kernels; the scalars stay on the device exactly as in the Jacobi case.
+// diag.z between the two update kernels; the scalars stay on the device exactly as in the Jacobi case.  precond(g, z, gz_partials) returns true
+// when it has already left the block partials of g . z (over the owned rows) in gz_partials.
 int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
         const DiagVec &diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info,
-        const std::function<void(const double *, double *)> *precond = nullptr, int *its_hint = nullptr) {
+        const std::function<bool(const double *, double *, double *)> *precond = nullptr, int *its_hint = nullptr) {
   hipStream_t s = c->stream;
   const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
   double *zbuf = const_cast<double *>(diag.z);
@@ -253,7 +254,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   apply(x, h, nullptr); ++applies;
   pcg_init_residual(s, g, h, b, diag.inert, n);
   la_dot_partials(s, b, b, n_own, part);
-  if (precond) (*precond)(g, zbuf);
+  if (precond) (void)(*precond)(g, zbuf, nullptr);
   pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
   pcg_scalars_sum(s, part, 3, red);
   allreduce_sum(c, red, 3);
@@ -277,7 +278,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
       ++applies;
       if (multi) { pcg_scalars_sum(s, part_dh, 1, red); allreduce_sum(c, red, 1); }
       pcg_update_g_fused(s, sc, (it - 1) & 1, g, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
-      if (precond) { (*precond)(g, zbuf); la_dot_partials(s, g, zbuf, n_own, part + kMaxPartials); }
+      if (precond && !(*precond)(g, zbuf, part + kMaxPartials)) la_dot_partials(s, g, zbuf, n_own, part + kMaxPartials);
       if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
       pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
@@ -823,6 +824,40 @@ void sync_source_vector(poro_ctx *c) {   // PORO_VEC_SOURCE_P = the assembled (r
   exchange_add(c, vec(c, PORO_VEC_SOURCE_P), c->n_p, c->comm.part.plane_p);
 }
 
+// lambda_max(D^-1 A_u) from the Lanczos tridiagonal of 25 Jacobi-preconditioned CG steps on a synthetic right-hand side (the constrained rows are
+// inert): the largest Ritz value approaches lambda_max from below within a fraction of a percent, far faster than a power iteration
+double estimate_lmax_u(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, const DiagVec &dj) {
+  hipStream_t s = c->stream; const int64_t n = c->n_u, n_own = owned(c, n, c->comm.part.plane_u);
+  std::vector<double> hv(n); for (int64_t i = 0; i < n; ++i) hv[i] = std::sin(0.731 * (double)i) + 0.3 * std::cos(0.013 * (double)i * (double)(i % 7));
+  DevBuf<double> r, z, p, ap; r.upload(hv); z.alloc(n); p.alloc(n); ap.alloc(n);
+  la_mask_zero(s, r.p, dj.inert, n);
+  la_cheb_first(s, z.p, r.p, dj, 1.0, n);                            // z = D^-1 r
+  la_copy(s, p.p, z.p, n);
+  double rz = dot_host(c, r.p, z.p, n_own);
+  const int K = 25; std::vector<double> al, be;
+  for (int k = 0; k < K && rz > 0; ++k) {
+    apply(p.p, ap.p, nullptr);
+    la_mask_zero(s, ap.p, dj.inert, n);
+    const double pap = dot_host(c, p.p, ap.p, n_own);
+    if (!(pap > 0)) break;
+    const double alpha = rz / pap;
+    la_axpy(s, r.p, -alpha, ap.p, n);
+    la_cheb_first(s, z.p, r.p, dj, 1.0, n);
+    const double rz_new = dot_host(c, r.p, z.p, n_own), beta = rz_new / rz;
+    al.push_back(alpha); be.push_back(beta);
+    la_xpby(s, p.p, beta, 1.0, z.p, n);                               // p = beta p + z
+    rz = rz_new;
+  }
+  const int m = (int)al.size();
+  if (m == 0) return 4.0;
+  std::vector<double> T((size_t)m * m, 0.0);
+  for (int k = 0; k < m; ++k) {
+    T[(size_t)k * m + k] = 1.0 / al[k] + (k > 0 ? be[k - 1] / al[k - 1] : 0.0);
+    if (k + 1 < m) T[(size_t)k * m + k + 1] = T[(size_t)(k + 1) * m + k] = std::sqrt(be[k]) / al[k];
+  }
+  return 1.05 * sym_lambda_max(m, T);
+}
+
 template <class F> int guarded(F &&f) {
   try { return f(); }
   catch (const std::exception &e) { g_err = e.what(); return -1; }
@@ -1037,7 +1072,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
         }
         if (ok) { c->diag_u_cls.upload(cls); c->diag_u_tab.upload(tab); }
       }
-      c->matrix_built = true; c->ilu_u_valid = false;
+      c->matrix_built = true; c->ilu_u_valid = false; c->cheb_lmax = 0;
     }
     {
       Timed tm(c, "assemble_u_rhs");
@@ -1072,6 +1107,7 @@ int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec
   if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
   if (which_system == 0 ? c->cons_u.n : c->cons_p.n) return 0;   // condensed operators exist at operator level only: Jacobi
   if (prec == PORO_PREC_SSOR || prec == PORO_PREC_ILU0) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
+  if (prec == PORO_PREC_CHEBYSHEV) return which_system == 0;
   if (prec == PORO_PREC_FDM && which_system == 1) return fdm_p_supported(c);
   if (prec == PORO_PREC_FDM) { analyse_fdm_u(c); return c->fdm_u_state == 1; }
   return 0;
@@ -1104,10 +1140,81 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       la_cons_reduce(c->stream, c->cons_u, y);
       return false;
     };
+    if (opts->preconditioner == PORO_PREC_CHEBYSHEV) {
+      // z = q(D^-1 A) D^-1 g with the Chebyshev polynomial q of degree m for the interval [lambda_max / ratio, lambda_max]: m operator applications
+      // without dot products; on 3D boxes (one rank) the recurrence runs inside the structured operator kernel
+      int m = opts->poly_degree > 0 ? opts->poly_degree : 4;
+      DiagVec dj; dj.full = c->dinv_u.p; dj.ncomp = c->dim; dj.inert = c->cons_u.inert.p;
+      if (c->diag_u_cls.p) { dj.cls = c->diag_u_cls.p; dj.tab = c->diag_u_tab.p; }
+      // lambda_max(D^-1 A): on a uniform box all cells share one element matrix and lambda_max <= lambda_max(diag(K_e)^-1 K_e) holds rigorously
+      // (x^T A x = sum_e x_e^T K_e x_e <= mu sum_e x_e^T diag(K_e) x_e = mu x^T D x) but is loose (3.8 against 2.5 for Q2 hexahedra), so the working
+      // value is the Lanczos estimate (+5 %) capped by it.  Only EVEN degrees are used: should an eigenvalue still exceed the assumed bound, it meets
+      // T_{m+1} outside [-1, 1], and q(lambda) lambda stays positive (the preconditioner SPD) exactly when m + 1 is odd
+      const bool have_bound = c->box.enabled && c->Ke.p && !c->cons_u.n;
+      if (m & 1) ++m;
+      if (!(c->cheb_lmax > 0)) {
+        if (have_bound) {
+          std::vector<double> ke((size_t)c->dpc_u * c->dpc_u);
+          PORO_HIP(hipMemcpyAsync(ke.data(), c->Ke.p, ke.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+          c->cheb_lmax = std::min(jacobi_scaled_lambda_max(c->dpc_u, ke), estimate_lmax_u(c, apply, dj));   // the element bound is rigorous but loose
+        } else c->cheb_lmax = estimate_lmax_u(c, apply, dj); if (std::getenv("PORO_CHEB_VERBOSE")) std::fprintf(stderr, "[poro] lambda_max(D^-1 A_u) ~ %.6f\n", c->cheb_lmax); }
+      double ratio = opts->omega;
+      if (!(ratio > 1.0)) {   // default: a few times lambda_min, which scales with h^2 (calibrated on box runs of 8^3 .. 72^3 cells)
+        int nmax = 1; for (int k = 0; k < c->dim; ++k) nmax = std::max(nmax, c->box.enabled ? c->box.n[k] : (int)std::lround(std::pow((double)c->n_cells, 1.0 / c->dim)));
+        ratio = std::min(400.0, std::max(10.0, (c->k_u == 2 ? 0.2 : 0.05) * nmax * nmax));
+      }
+      const double lmax = c->cheb_lmax, lmin = lmax / ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+      if (!c->cheb_z.p) { c->cheb_z.alloc(c->n_u); c->cheb_z.zero(c->stream); c->cheb_t.alloc(c->n_u); c->cheb_t.zero(c->stream); }
+      if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
+      const bool fuse = mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && c->dim == 3 && kron_supported(c->dim, c->k_u) && !c->comm.multi() && c->diag_u_cls.p && !c->cons_u.n &&
+                        !std::getenv("PORO_CHEB_UNFUSED");
+      const int64_t n_own = owned(c, c->n_u, c->comm.part.plane_u);
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *gz_partials) {
+        Timed tm(c, "precondition_u_chebyshev");
+        hipStream_t s = c->stream;
+        double *X[2] = {(m % 2 == 0) ? z : c->cheb_z.p, (m % 2 == 0) ? c->cheb_z.p : z};   // z_{j+1} lands in X[j & 1]; the last one (j = m) in z
+        la_cheb_first(s, X[0], g, dj, 1.0 / theta, c->n_u);
+        double rho = 1.0 / sigma; bool dot_done = false;
+        // (the device-side "solve finished" flag may only gate launches inside the iteration: before pcg_scalars_start it still holds the previous solve's state)
+        const PcgScalars *pstate = gz_partials ? c->scal.p : nullptr;
+        for (int j = 1; j <= m; ++j) {
+          const double rho_new = 1.0 / (2.0 * sigma - rho), c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+          rho = rho_new;
+          double *zj = X[(j - 1) & 1], *zn = X[j & 1];
+          const bool last = j == m;
+          if (fuse) {
+            KronCheb kc; kc.g = g; kc.zprev = zn; kc.znew = zn; kc.c1 = c1; kc.c2 = c2; kc.cls = c->diag_u_cls.p; kc.tab = c->diag_u_tab.p; kc.first = j == 1 ? 1 : 0;
+            double *dp = (last && gz_partials) ? gz_partials : nullptr;
+            if (dp) PORO_HIP(hipMemsetAsync(dp, 0, kMaxPartials * sizeof(double), s));
+            int slots;
+            if (c->timing) { Timer &t = c->timers["apply_u_chebyshev_fused"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
+                             slots = kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, dp, e0, e1, pstate, &kc); t.pending.emplace_back(e0, e1); t.launches++; }
+            else slots = kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, dp, nullptr, nullptr, pstate, &kc);
+            if (dp && slots > 0) dot_done = true;
+          } else {
+            apply(zj, c->cheb_t.p, nullptr);
+            la_cheb_step(s, zn, zj, j == 1 ? nullptr : zn, g, c->cheb_t.p, dj, c1, c2, c->n_u, n_own, (last && gz_partials) ? gz_partials : nullptr);
+            if (last && gz_partials) dot_done = true;
+          }
+          ++c->cheb_applies;
+        }
+        return dot_done;
+      };
+      DiagVec dz = dj; dz.z = c->wz_u.p;
+      const int64_t applies0 = c->cheb_applies;
+      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_cheb_u);
+      // useful operator applications: one per CG iteration + the initial residual, and m per preconditioner call (one call per iteration + the first direction)
+      if (info) info->operator_applications = (int64_t)info->iterations + 1 + (int64_t)m * (info->iterations + 1);
+      (void)applies0;
+      la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
+      la_cons_expand(c->stream, c->cons_u, vec(c, PORO_VEC_U), true);
+      PORO_HIP(hipStreamSynchronize(c->stream));
+      return rc;
+    }
     if (opts->preconditioner == PORO_PREC_FDM) {
       // z = blockdiag(A_cc)^-1 g by fast diagonalisation: the same device-controlled SolverCG recurrence with an explicit preconditioner vector
       build_fdm_u(c);
-      const std::function<void(const double *, double *)> P = [&](const double *g, double *z) { fdm_precondition_u(c, g, z); };
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { fdm_precondition_u(c, g, z); return false; };
       DiagVec dz; dz.full = c->dinv_u.p; dz.ncomp = c->dim; dz.inert = c->dir_mask.p; dz.z = c->wz_u.p;
       const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_fdm_u);
       la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
@@ -1185,7 +1292,7 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       build_fdm_p(c);
       const double kk[3] = {jk, jk, jk};
       if (!c->wz_p.p) c->wz_p.alloc(c->n_p);
-      const std::function<void(const double *, double *)> P = [&](const double *g, double *z) { fdm_precondition_p(c, ja, kk, g, z); };
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { fdm_precondition_p(c, ja, kk, g, z); return false; };
       DiagVec dz; dz.full = c->dinv_J.p; dz.z = c->wz_p.p;
       return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
     }
@@ -1259,7 +1366,7 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
       build_fdm_p(c);
       const double kk[3] = {0, 0, 0};
       if (!c->wz_p.p) c->wz_p.alloc(c->n_p);
-      const std::function<void(const double *, double *)> P = [&](const double *g, double *z) { fdm_precondition_p(c, 1.0, kk, g, z); };
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { fdm_precondition_p(c, 1.0, kk, g, z); return false; };
       DiagVec dz; dz.full = c->dinv_M.p; dz.z = c->wz_p.p;
       return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
     }

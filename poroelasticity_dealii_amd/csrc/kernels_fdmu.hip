@@ -435,6 +435,21 @@ void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::ve
   }
 }
 
+double sym_lambda_max(int n, const std::vector<double> &A) {
+  std::vector<double> B = A, V, w; jacobi_eig(n, B, V, w);
+  double m = 0; for (double v : w) m = std::max(m, v);
+  return m;
+}
+// largest eigenvalue of D^-1/2 A D^-1/2 for a small dense symmetric matrix (row-major n x n), D = diag(A): the rigorous element-level bound
+// lambda_max(D^-1 A_global) <= max_e lambda_max(diag(A_e)^-1 A_e) of the Chebyshev preconditioner
+double jacobi_scaled_lambda_max(int n, const std::vector<double> &A) {
+  std::vector<double> B((size_t)n * n), V, w;
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) B[(size_t)i * n + j] = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]) / std::sqrt(A[(size_t)i * n + i] * A[(size_t)j * n + j]);
+  jacobi_eig(n, B, V, w);
+  double m = 0; for (double v : w) m = std::max(m, v);
+  return m;
+}
+
 namespace {
 // MFMA A-fragment order of the (nn x nn) matrix Tm (row-major; transposed access when `transpose`): [MT][KK][64], lane -> row 16 mt + (lane & 15), column 4 kk + (lane >> 4)
 template <class TC> void upload_fragments(DevBuf<double> &dst, const std::vector<double> &Tm, int nn, bool transpose) {

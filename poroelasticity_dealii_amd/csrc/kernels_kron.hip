@@ -49,6 +49,7 @@ struct KronArgs {
   const uint8_t *nodemask; int constrained, mask_anywhere;
   double *dot_partials;   // optional: per-workgroup partial of x.y over the free rows (x is zero on the Dirichlet columns after masking)
   const PcgScalars *pcg;  // optional: inside PCG the launch is a no-op once the solve has finished (the host enqueues iterations in batches)
+  KronCheb cheb;          // CHEB kernels: the Chebyshev recurrence is applied where the product leaves the registers (see kron_tile's emit)
 };
 
 __device__ inline int64_t xcd_remap(int64_t bid, int64_t n) {
@@ -75,7 +76,7 @@ __device__ const signed char kRows64[16] = {2, 4, 6, 8, 3, 5, 7, 9, 10, 11, 12, 
 __device__ const signed char kRows32a[16] = {2, 6, 10, 14, 3, 7, 11, 15, 18, 22, 26, 27, 19, 23, 0, 1};
 __device__ const signed char kRows32b[16] = {4, 8, 12, 16, 5, 9, 13, 17, 20, 24, 28, 29, 21, 25, 30, 31};
 
-template <int TXN>
+template <int TXN, bool CHEB>
 __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__restrict__ x, double *__restrict__ y, double *L, const int X0, const int tyi, const int zc) {
   constexpr int RPW = 64 / TXN, TYR = 16 * RPW, VY = TYR - 4;   // rows per wave, rows per tile, valid rows
   static_assert(TXN * TYR == kTileNodes, "tile");
@@ -187,7 +188,18 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
     };
     const double (&xc)[3] = oddz ? W3 : W2;            // this plane's (masked) input values, for the fused x.y
     const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
-    auto emit = [&](int c, double v) { if (out) { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); } };   // Dirichlet rows: see the header
+    // CHEB: x is the Chebyshev iterate z_j; instead of A z_j the kernel stores z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 D^-1 (g - A z_j) (z_{j+1} may
+    // overwrite z_{j-1}: every entry is read and written by its own thread only) and accumulates g . z_{j+1}.  Dirichlet dofs have D^-1 = 0 and z = 0.
+    const double *ctab = nullptr;
+    if constexpr (CHEB) ctab = a.cheb.tab + (out ? 3u * a.cheb.cls[d0 / 3] : 0u);
+    auto emit = [&](int c, double v) {
+      if (!out) return;
+      if constexpr (CHEB) {
+        const double gi = a.cheb.g[d0 + c], zp = a.cheb.first ? 0.0 : a.cheb.zprev[d0 + c];
+        const double zn = fma(a.cheb.c2 * ctab[c], gi - v, fma(a.cheb.c1, xc[c] - zp, xc[c]));
+        a.cheb.znew[d0 + c] = zn; dot_acc = fma(gi, zn, dot_acc);
+      } else { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); }   // Dirichlet rows: see the header
+    };
 
     if (!has_w) {
       if (halo_wave) return;
@@ -269,8 +281,18 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];                            // [2 buffers][9 fields][1024 nodes of the tile plane]
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;  // uniform over the grid: written by the previous launches only
   const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);  // workgroup-uniform: either tile shape, never both
-  if (tile < a.nA) kron_tile<64>(a, x, y, L, 60 * (tile / (a.nzc * a.nty64)) - 2, (tile / a.nzc) % a.nty64, tile % a.nzc);
-  else { const int t = tile - a.nA; kron_tile<32>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+  if (tile < a.nA) kron_tile<64, false>(a, x, y, L, 60 * (tile / (a.nzc * a.nty64)) - 2, (tile / a.nzc) % a.nty64, tile % a.nzc);
+  else { const int t = tile - a.nA; kron_tile<32, false>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+}
+// the same sweep with the Chebyshev recurrence fused into the stores (polynomial preconditioner of the displacement CG: no vector kernels and no
+// reductions between the operator applications of one preconditioner call)
+__global__ void __launch_bounds__(1024)
+k_kron3_q2_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ double L[];
+  if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
+  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
+  if (tile < a.nA) kron_tile<64, true>(a, x, y, L, 60 * (tile / (a.nzc * a.nty64)) - 2, (tile / a.nzc) % a.nty64, tile % a.nzc);
+  else { const int t = tile - a.nA; kron_tile<32, true>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
 }
 
 
@@ -279,7 +301,7 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
 //   M (1, cM, 1), cM = 2(mL+mR);  K (-1, cK, -1), cK = mL+mR;  O (1, ., -1);  D = mL - mR.
 // Every node is a vertex node: 3-plane register window, one plane per barrier, halo of one node / row / plane.  Tiles: 64 lanes x 16
 // rows (62 x 14 valid) and 32 lanes x 32 rows (30 x 30 valid).
-template <int TXN>
+template <int TXN, bool CHEB>
 __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__restrict__ x, double *__restrict__ y, double *L, const int X0, const int tyi, const int zc) {
   constexpr int RPW = 64 / TXN, TYR = 16 * RPW, VY = TYR - 2;
   const int tid = threadIdx.x;
@@ -350,7 +372,16 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
       return fma(cKx, FK, fma(cMx, FM, cDx * FD)) + wave_up1(t1 + FO) + wave_dn1(t1 - FO);   // from i-1 and i+1
     };
     const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
-    auto emit = [&](int c, double v) { if (out) { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); } };
+    const double *ctab = nullptr;
+    if constexpr (CHEB) ctab = a.cheb.tab + (out ? 3u * a.cheb.cls[d0 / 3] : 0u);
+    auto emit = [&](int c, double v) {
+      if (!out) return;
+      if constexpr (CHEB) {      // see kron_tile
+        const double gi = a.cheb.g[d0 + c], zp = a.cheb.first ? 0.0 : a.cheb.zprev[d0 + c];
+        const double zn = fma(a.cheb.c2 * ctab[c], gi - v, fma(a.cheb.c1, xc[c] - zp, xc[c]));
+        a.cheb.znew[d0 + c] = zn; dot_acc = fma(gi, zn, dot_acc);
+      } else { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); }
+    };
 
     if (!has_w) {
       if (!halo_wave) {
@@ -425,8 +456,16 @@ k_kron3_q1(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
   const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
-  if (tile < a.nA) kron_tile_q1<64>(a, x, y, L, 62 * (tile / (a.nzc * a.nty64)) - 1, (tile / a.nzc) % a.nty64, tile % a.nzc);
-  else { const int t = tile - a.nA; kron_tile_q1<32>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+  if (tile < a.nA) kron_tile_q1<64, false>(a, x, y, L, 62 * (tile / (a.nzc * a.nty64)) - 1, (tile / a.nzc) % a.nty64, tile % a.nzc);
+  else { const int t = tile - a.nA; kron_tile_q1<32, false>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+}
+__global__ void __launch_bounds__(1024)
+k_kron3_q1_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ double L[];
+  if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
+  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
+  if (tile < a.nA) kron_tile_q1<64, true>(a, x, y, L, 62 * (tile / (a.nzc * a.nty64)) - 1, (tile / a.nzc) % a.nty64, tile % a.nzc);
+  else { const int t = tile - a.nA; kron_tile_q1<32, true>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
 }
 
 // ---- 2D (Q2 and Q1): A_xx = (l+2G) Kx (x) My + G Mx (x) Ky,  A_yy = G Kx (x) My + (l+2G) Mx (x) Ky,
@@ -550,9 +589,12 @@ void kron_prepare_device() {
   const int lds = (int)((size_t)NFLD * kTileNodes * sizeof(double));
   PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q1, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2_cheb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q1_cheb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 }
 
-int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1, const PcgScalars *pcg) {
+int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1, const PcgScalars *pcg,
+               const KronCheb *cheb) {
   static bool checked = false;
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
@@ -605,7 +647,11 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   const bool fuse = dot_partials && nblk <= kMaxPartials / 2;
   a.dot_partials = fuse ? dot_partials : nullptr; a.pcg = pcg;
   // ev0 / ev1 (optional): timestamps at the start / end of THIS dispatch, so the measured time is the kernel's own duration
-  if (ku == 2) hipExtLaunchKernelGGL(k_kron3_q2, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
+  if (cheb) {
+    a.cheb = *cheb;
+    if (ku == 2) hipExtLaunchKernelGGL(k_kron3_q2_cheb, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
+    else hipExtLaunchKernelGGL(k_kron3_q1_cheb, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
+  } else if (ku == 2) hipExtLaunchKernelGGL(k_kron3_q2, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
   else hipExtLaunchKernelGGL(k_kron3_q1, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
   return (dot_partials && !fuse) ? -nblk : nblk;
 }

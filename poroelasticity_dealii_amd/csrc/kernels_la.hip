@@ -368,6 +368,21 @@ template <int NC> __global__ void k_pcg_update_d_fused(PcgScalars *sc, int parit
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->gh2[parity ^ 1] = gz; }
 }
+template <int NC> __global__ void k_cheb_first(double *z, const double *g, DiagRef D, double scale, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) z[i] = scale * diag_at<NC>(D, i) * g[i];
+}
+template <int NC> __global__ void k_cheb_step(double *znew, const double *zj, const double *zprev, const double *g, const double *Az, DiagRef D, double c1, double c2, int64_t n,
+                                              int64_t n_owned, double *gz_partials) {
+  __shared__ double sh[4];
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double z = zj[i], zp = zprev ? zprev[i] : 0.0, gi = g[i];
+    const double zn = fma(c2 * diag_at<NC>(D, i), gi - Az[i], fma(c1, z - zp, z));
+    znew[i] = zn;
+    if (i < n_owned) acc = fma(gi, zn, acc);
+  }
+  if (gz_partials) { acc = block_sum(acc, sh); store_partial(gz_partials, acc); }
+}
 template <class F> void dispatch_lanes(int L, F &&f) {
   switch (L) {
     case 2: f(std::integral_constant<int, 2>()); break;
@@ -488,6 +503,23 @@ void la_rhs_u_finish(hipStream_t s, double *rhs, const double *lift, const doubl
 }
 // dictionary form only for 2 / 3 components and 32-bit dof indices
 static int diag_nc(const DiagVec &dv, int64_t n) { return (dv.cls && (dv.ncomp == 2 || dv.ncomp == 3) && n < (int64_t)4000000000ll) ? dv.ncomp : 0; }
+void la_cheb_first(hipStream_t s, double *z, const double *g, const DiagVec &dv, double scale, int64_t n) {
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, nullptr};
+  switch (diag_nc(dv, n)) {
+    case 2: hipLaunchKernelGGL(k_cheb_first<2>, grid_for(n), kBlock, 0, s, z, g, D, scale, n); break;
+    case 3: hipLaunchKernelGGL(k_cheb_first<3>, grid_for(n), kBlock, 0, s, z, g, D, scale, n); break;
+    default: hipLaunchKernelGGL(k_cheb_first<0>, grid_for(n), kBlock, 0, s, z, g, D, scale, n);
+  }
+}
+void la_cheb_step(hipStream_t s, double *znew, const double *zj, const double *zprev, const double *g, const double *Az, const DiagVec &dv, double c1, double c2, int64_t n,
+                  int64_t n_owned, double *gz_partials) {
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, nullptr};
+  switch (diag_nc(dv, n)) {
+    case 2: hipLaunchKernelGGL(k_cheb_step<2>, reduce_grid(n), kBlock, 0, s, znew, zj, zprev, g, Az, D, c1, c2, n, n_owned, gz_partials); break;
+    case 3: hipLaunchKernelGGL(k_cheb_step<3>, reduce_grid(n), kBlock, 0, s, znew, zj, zprev, g, Az, D, c1, c2, n, n_owned, gz_partials); break;
+    default: hipLaunchKernelGGL(k_cheb_step<0>, reduce_grid(n), kBlock, 0, s, znew, zj, zprev, g, Az, D, c1, c2, n, n_owned, gz_partials);
+  }
+}
 void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, const uint8_t *inert, int64_t n) {
   hipLaunchKernelGGL(k_pcg_init_residual, grid_for(n), kBlock, 0, s, g, Ax, b, inert, n);
 }

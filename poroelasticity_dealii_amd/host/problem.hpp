@@ -49,6 +49,7 @@ struct RunControls {
   bool incremental_strain = false;                                  // true = storage term against the previous step, alpha (eps_v - eps_v^n) / dt, instead of the initial state eps_v0 (:317, :361-363)
   bool corrected_postprocessing = false;                            // false = the reference's output (shear RHS never assembled, 2D "sigma_yy" shows sigma_xx); true = both fixed
   std::string output_dir;                                           // "" = no files; the reference always writes ./solution/solution-NNNN.vtk (:285-290)
+  int chebyshev_degree = 0; double chebyshev_ratio = 0.0;           // PORO_PREC_CHEBYSHEV: 0 = the library's defaults
   int preconditioner_p = -1;                                        // pressure / projection solves; -1 = fast diagonalisation where the context supports it, else Jacobi
 };
 
@@ -248,6 +249,7 @@ template <int dim> class PoroElasticProblem {
     displacement_solver.control.abs_tol = rc.abs_tol_u; displacement_solver.control.rel_tol = rc.rel_tol_u; displacement_solver.control.stop_rule = rc.stop_rule_u;
     displacement_solver.control.max_iter = pressure_solver.control.max_iter = strain_projector.control.max_iter = rc.max_iter;
     displacement_solver.control.preconditioner = rc.preconditioner;
+    if (rc.preconditioner == PORO_PREC_CHEBYSHEV) { displacement_solver.control.omega = rc.chebyshev_ratio; displacement_solver.control.poly_degree = rc.chebyshev_degree; }
     pressure_solver.control.preconditioner = strain_projector.control.preconditioner =
         rc.preconditioner == PORO_PREC_SSOR ? PORO_PREC_SSOR : rc.preconditioner_p >= 0 ? rc.preconditioner_p
         : poro_supports_preconditioner(context(), 1, PORO_PREC_FDM) ? PORO_PREC_FDM : PORO_PREC_JACOBI;

@@ -45,7 +45,7 @@ def main():
     else:
         # hip_mf_fdm: the displacement solve uses the block fast-diagonalisation preconditioner (all-to-all of column groups in the partitioned direction)
         R = pk.Runner(P, device=0, operator_mode=pk.OP_CSR if backend == "hip_csr" else pk.OP_MATRIX_FREE, p_init=REF["p_init"], dt=REF["dt"], max_it=20000,
-                      prec=pk.PREC_FDM if backend == "hip_mf_fdm" else pk.PREC_JACOBI)
+                      prec=pk.PREC_FDM if backend == "hip_mf_fdm" else pk.PREC_CHEBYSHEV if backend == "hip_mf_cheb" else pk.PREC_JACOBI)
         O = R.ctx
         O.comm_callbacks(allreduce, sendrecv)
         R.initialize()

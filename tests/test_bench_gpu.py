@@ -32,9 +32,12 @@ def test_single_rank_line():
     assert "workload" in d["config"]
     assert len(d["cg_iterations_u"]) == 1 and min(d["cg_iterations_u"][0]) > 0     # every timed step does a live displacement solve
     assert "reduction" in d["config"]["stopping_rule_u"].lower() or "g_0" in d["config"]["stopping_rule_u"]
+    assert set(d["time_to_solution"]) == {"jacobi", "chebyshev", "block_fdm"}
     tts = d["time_to_solution"]["block_fdm"]
     assert "error" not in tts, tts
     assert max(tts["cg_iterations_u"][0]) <= 40 and tts["applications_precondition_u"] > 0
+    assert d["time_to_solution"]["chebyshev"]["cg_iterations_u"][0][0] < d["time_to_solution"]["jacobi"]["cg_iterations_u"][0][0]
+    assert "cheb" in d["roofline"]["kernel"] and d["roofline"]["plain_operator"]["avg_launch_us"] > 0
 
 
 def test_live_steps_do_not_depend_on_the_window():

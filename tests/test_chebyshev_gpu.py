@@ -1,0 +1,84 @@
+"""Chebyshev polynomial preconditioner of the displacement CG (PORO_PREC_CHEBYSHEV; the preconditioner slot of
+PoroElasticDisplacementSolver<dim>::solve, PoroElasticDisplacementSolver.h:302-305): same converged u as the oracle's SSOR-CG, far fewer CG
+iterations than Jacobi, and the recurrence fused into the structured operator kernel gives the same iterates as the unfused one."""
+import numpy as np
+import pytest
+
+import poroelasticity_dealii_amd as pk
+import oracle_py
+from common import REF, box_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(G, prec, **kw):
+    G.fill(pk.VEC_U, 0.0)
+    rc, info = G.disp_solve(abs_tol=1e-14, rel_tol=1e-11, max_iter=20000, prec=prec, **kw)
+    assert rc == 0
+    return G.get(pk.VEC_U), info
+
+
+@pytest.mark.parametrize("dim,n,deg,mode", [(3, 6, 2, pk.OP_MATRIX_FREE), (3, (7, 5, 6), 1, pk.OP_MATRIX_FREE), (2, 12, 2, pk.OP_MATRIX_FREE), (3, 4, 2, pk.OP_CSR), (2, 10, 1, pk.OP_CSR)], ids=str)
+def test_chebyshev_cg_matches_the_oracle(dim, n, deg, mode, monkeypatch):
+    P = box_problem(dim, n, deg)
+    O = oracle_py.Oracle(P, hoisted=True)
+    G = pk.Context(P, 0, mode)
+    try:
+        p = REF["p_init"] * (1 + 0.3 * np.sin(0.37 * np.arange(G.n_p)))
+        for S in (O, G):
+            S.set(pk.VEC_P, p); S.disp_assemble_system(True)
+        assert O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=20000)[0] == 0
+        u0 = O.get(pk.VEC_U)
+        uj, ij = solve(G, pk.PREC_JACOBI)
+        for m in (2, 4):
+            uc, ic = solve(G, pk.PREC_CHEBYSHEV, poly_degree=m)
+            assert np.linalg.norm(uc - u0) <= 1e-9 * np.linalg.norm(u0)
+            assert ic.iterations < ij.iterations and ic.operator_applications == (m + 1) * (ic.iterations + 1)
+            print(f"{dim}D n={n} Q{deg} m={m}: Chebyshev {ic.iterations} its / {ic.operator_applications} applications, Jacobi {ij.iterations} its")
+            assert ic.operator_applications <= 1.7 * ij.operator_applications        # the polynomial costs few extra operator applications
+        if mode == pk.OP_MATRIX_FREE and dim == 3:
+            # the fused recurrence (inside k_kron3_*) against the elementwise kernel after the plain operator
+            monkeypatch.setenv("PORO_CHEB_UNFUSED", "1")
+            uu, iu = solve(G, pk.PREC_CHEBYSHEV, poly_degree=4)
+            monkeypatch.delenv("PORO_CHEB_UNFUSED")
+            assert iu.iterations == ic.iterations and np.abs(uu - uc).max() <= 1e-12 * np.abs(uc).max()
+    finally:
+        G.close(); O.close(); P.close()
+
+
+def test_chebyshev_time_steps_match_the_oracle():
+    P = box_problem(3, 4, 2)
+    O = oracle_py.Oracle(P, hoisted=True)
+    try:
+        t0, _ = O.run(2, REF["p_init"], REF["dt"], max_it=5000)
+        t1, G = pk.run_problem(P, 2, REF["p_init"], REF["dt"], operator_mode=pk.OP_MATRIX_FREE, max_it=5000, prec=pk.PREC_CHEBYSHEV, cheb_degree=2)
+        assert np.array_equal(t1[:, :3], t0[:, :3])
+        assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-8 * np.linalg.norm(O.get(pk.VEC_U))
+        assert np.abs(G.get(pk.VEC_P) - O.get(pk.VEC_P)).max() <= 1e-10 * np.abs(O.get(pk.VEC_P)).max()
+        G.close()
+    finally:
+        O.close(); P.close()
+
+
+def test_chebyshev_at_config_4_size():
+    """BASELINE config 4 (72^3 Q2/Q1): operator applications and wall time of one displacement solve, Jacobi vs Chebyshev (reported; asserts the gain)"""
+    P = box_problem(3, 72, 2)
+    G = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    try:
+        p = REF["p_init"] * (1 + 0.3 * np.sin(0.37 * np.arange(G.n_p)))
+        G.set(pk.VEC_P, p); G.disp_assemble_system(True)
+        G.fill(pk.VEC_U, 0.0)
+        rc, ij = G.disp_solve(abs_tol=1e-12, rel_tol=1e-10, max_iter=20000, prec=pk.PREC_JACOBI)
+        assert rc == 0
+        uj = G.get(pk.VEC_U)
+        for m, ratio in [(4, 0), (4, 100), (4, 200), (6, 200), (8, 400)]:
+            G.fill(pk.VEC_U, 0.0)
+            G.disp_solve(abs_tol=1e-12, rel_tol=1e-10, max_iter=20000, prec=pk.PREC_CHEBYSHEV, poly_degree=m, omega=float(ratio))   # warm-up (lambda_max estimate, buffers)
+            G.fill(pk.VEC_U, 0.0)
+            rc, ic = G.disp_solve(abs_tol=1e-12, rel_tol=1e-10, max_iter=20000, prec=pk.PREC_CHEBYSHEV, poly_degree=m, omega=float(ratio))
+            assert rc == 0
+            print(f"config 4: Chebyshev m={m} ratio={ratio}: {ic.iterations} its, {ic.operator_applications} applications, {ic.seconds * 1e3:.1f} ms "
+                  f"({ic.seconds / ic.operator_applications * 1e6:.1f} us / application)   [Jacobi {ij.iterations} its, {ij.seconds * 1e3:.1f} ms, {ij.seconds / ij.operator_applications * 1e6:.1f} us / application]")
+            assert np.linalg.norm(G.get(pk.VEC_U) - uj) <= 1e-7 * np.linalg.norm(uj)
+    finally:
+        G.close(); P.close()

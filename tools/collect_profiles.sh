@@ -1,0 +1,26 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): rocprofv3 kernel stats of the default bench run, PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes, as the
+# guide prescribes) of the structured operator kernels and of the bench run, and the CSR / assembly micro-benchmarks.  Output: gpurun_out/profiles_r02/.
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/profiles_r02
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+TAG=${1:-r02}
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$TAG -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_stderr.log || exit 1
+cp $(ls $OUT/stats_$TAG/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $ROOT/tools/bench_ops.py 3,72,2,mf 3,99,1,mf > $OUT/${TAG}_ops_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $ROOT/tools/bench_ops.py 3,72,2,mf 3,99,1,mf > $OUT/${TAG}_ops_write.log 2>&1 || exit 1
+FD=$(dirname $(ls $OUT/pmc_fetch_$TAG/*/*counter_collection.csv | head -1)); WD=$(dirname $(ls $OUT/pmc_write_$TAG/*/*counter_collection.csv | head -1))
+python3 $ROOT/tools/pmc_summary.py $FD $WD $OUT/${TAG}_pmc_traffic_raw.json > $OUT/${TAG}_pmc_traffic.txt || exit 1
+python3 - <<PY
+import json, hashlib
+d = json.load(open("$OUT/${TAG}_pmc_traffic_raw.json"))
+d["kernel_source_sha16"] = hashlib.sha256(open("$ROOT/poroelasticity_dealii_amd/csrc/kernels_kron.hip", "rb").read()).hexdigest()[:16]
+d["how"] = "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of tools/bench_ops.py 3,72,2,mf 3,99,1,mf; read bytes = 2 x FETCH_SIZE x 1024 (gfx950), tools/pmc_summary.py"
+json.dump(d, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1)
+PY
+python3 $ROOT/tools/asm_bench.py 3,32,2 3,48,2 2,336,2 > $OUT/${TAG}_csr_asm_spmv.jsonl 2> $OUT/${TAG}_csr_asm_stderr.log
+python3 $ROOT/tools/fdmu_bench.py > $OUT/${TAG}_fdmu_apply.txt 2>&1
+rm -rf $OUT/stats_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
+ls -la $OUT
