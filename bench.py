@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--prec", choices=["chebyshev", "jacobi"], default="chebyshev",
                     help="preconditioner of the displacement CG in the headline run: chebyshev = Chebyshev polynomial around Jacobi, on 3D boxes fused into the operator kernel "
                          "(the other one and the block fast diagonalisation are measured as well and reported under time_to_solution)")
-    ap.add_argument("--cheb-degree", type=int, default=4)
+    ap.add_argument("--cheb-degree", type=int, default=6)
     ap.add_argument("--max-iter", type=int, default=50000)
     ap.add_argument("--cpu-n", type=int, default=9, help="cells per direction of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -155,7 +155,7 @@ typedef struct poro_solver_opts {
   int32_t preconditioner;  /* PORO_PREC_* */
   double  omega;           /* relaxation of PORO_PREC_SSOR: 1.2 displacement (:303), 1.0 pressure / projection (:178, StrainProjector.h:212) */
   int32_t stop_rule;       /* PORO_STOP_* */
-  int32_t poly_degree;     /* PORO_PREC_CHEBYSHEV: operator applications per preconditioner call (<= 0: 4); `omega` then holds the ratio lambda_max / a of
+  int32_t poly_degree;     /* PORO_PREC_CHEBYSHEV: operator applications per preconditioner call (<= 0: 6; odd values are rounded up); `omega` then holds the ratio lambda_max / a of
                               the interval [a, lambda_max] the polynomial is built for (<= 0: a mesh-size based default) */
 } poro_solver_opts;
 enum { PORO_STOP_RHS = 0, PORO_STOP_REDUCTION = 1 };

@@ -46,7 +46,8 @@ struct PcgScalars {
 // per node + table[class][component] of reciprocals
 // reciprocal Jacobi diagonal; a ZERO entry marks an inert (Dirichlet) dof that PCG leaves alone; `inert` is the same set as a byte mask
 struct DiagVec { const double *full = nullptr; const uint8_t *cls = nullptr; const double *tab = nullptr; int ncomp = 1; const uint8_t *inert = nullptr;
-                 const double *z = nullptr; /* explicit preconditioner: z = P^-1 g is supplied as a vector (pcg() fills it between the two update kernels) */ };
+                 const double *z = nullptr; /* explicit preconditioner: z = P^-1 g is supplied as a vector (pcg() fills it between the two update kernels) */
+                 double *z1_out = nullptr; double z1_scale = 0; /* optional: the residual update also stores z1_scale * D^-1 g (first Chebyshev iterate) */ };
 
 struct FeTablesDev {   // device copies of poro_fe_tables
   int nq_u, nq_p, nq_f, ns_u, ns_p;

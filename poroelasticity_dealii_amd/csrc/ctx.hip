@@ -1143,7 +1143,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     if (opts->preconditioner == PORO_PREC_CHEBYSHEV) {
       // z = q(D^-1 A) D^-1 g with the Chebyshev polynomial q of degree m for the interval [lambda_max / ratio, lambda_max]: m operator applications
       // without dot products; on 3D boxes (one rank) the recurrence runs inside the structured operator kernel
-      int m = opts->poly_degree > 0 ? opts->poly_degree : 4;
+      int m = opts->poly_degree > 0 ? opts->poly_degree : 6;
       DiagVec dj; dj.full = c->dinv_u.p; dj.ncomp = c->dim; dj.inert = c->cons_u.inert.p;
       if (c->diag_u_cls.p) { dj.cls = c->diag_u_cls.p; dj.tab = c->diag_u_tab.p; }
       // lambda_max(D^-1 A): on a uniform box all cells share one element matrix and lambda_max <= lambda_max(diag(K_e)^-1 K_e) holds rigorously
@@ -1173,7 +1173,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         Timed tm(c, "precondition_u_chebyshev");
         hipStream_t s = c->stream;
         double *X[2] = {(m % 2 == 0) ? z : c->cheb_z.p, (m % 2 == 0) ? c->cheb_z.p : z};   // z_{j+1} lands in X[j & 1]; the last one (j = m) in z
-        la_cheb_first(s, X[0], g, dj, 1.0 / theta, c->n_u);
+        if (!gz_partials) la_cheb_first(s, X[0], g, dj, 1.0 / theta, c->n_u);   // inside the iteration z_1 = D^-1 g / theta was stored by the residual update (DiagVec::z1_out)
         double rho = 1.0 / sigma; bool dot_done = false;
         // (the device-side "solve finished" flag may only gate launches inside the iteration: before pcg_scalars_start it still holds the previous solve's state)
         const PcgScalars *pstate = gz_partials ? c->scal.p : nullptr;
@@ -1201,6 +1201,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         return dot_done;
       };
       DiagVec dz = dj; dz.z = c->wz_u.p;
+      dz.z1_out = (m % 2 == 0) ? c->wz_u.p : c->cheb_z.p; dz.z1_scale = 1.0 / theta;
       const int64_t applies0 = c->cheb_applies;
       const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_cheb_u);
       // useful operator applications: one per CG iteration + the initial residual, and m per preconditioner call (one call per iteration + the first direction)

@@ -238,7 +238,8 @@ __global__ void k_xpby(double *y, double a, double b, const double *x, int64_t n
 // ---- PCG (deal.II SolverCG structure: g = A x - b, d = -P^-1 g) ----------------------------------
 // INVERSE Jacobi diagonal (z = g * dinv: no fp64 division in the streaming kernels) either as a full vector or
 // dictionary-compressed: class byte per node (ncomp dofs each) + table[class][comp]
-struct DiagRef { const double *full; const uint8_t *cls; const double *tab; int ncomp; const double *z; };   // z != null: explicit z = P^-1 g computed by the caller
+struct DiagRef { const double *full; const uint8_t *cls; const double *tab; int ncomp; const double *z;   // z != null: explicit z = P^-1 g computed by the caller
+                 double *z1_out = nullptr; double z1_scale = 0; };
 // NC = components per node of the dictionary form (0: full vector); NC is a template parameter so that i / NC is a multiply
 template <int NC> __device__ inline double diag_at(const DiagRef &D, int64_t i) {
   if constexpr (NC == 0) return D.full[i];
@@ -315,6 +316,7 @@ template <int NC> __global__ void k_pcg_update_g_fused(PcgScalars *sc, int parit
   // a zero reciprocal diagonal marks an inert (Dirichlet) dof: its residual stays exactly zero whatever the operator wrote into h there
   auto one = [&](int64_t i, double &gi) {
     const double Di = diag_at<NC>(D, i);
+    if (D.z1_out) D.z1_out[i] = Di == 0.0 ? 0.0 : D.z1_scale * Di * gi;          // first iterate of the polynomial preconditioner rides with the residual update
     if (Di == 0.0) { gi = 0.0; return; }
     if (i < n_owned) { gg += gi * gi; if (!D.z) gz += gi * (prec ? gi * Di : gi); }   // explicit preconditioner: g.z follows in its own dot kernel once z = P^-1 g exists
   };
@@ -355,7 +357,8 @@ template <int NC> __global__ void k_pcg_update_d_fused(PcgScalars *sc, int parit
   for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n2; q += (int64_t)gridDim.x * kBlock) {
     // x is touched once per iteration and nowhere else: non-temporal accesses keep it from evicting d, g and h (3 x 73 MB at config 4),
     // which then stay resident in the 256 MB memory-side cache between the three kernels of an iteration (measured: -19 us / iteration)
-    const double2 gv = g2[q]; double2 dv = d2[q], xv;
+    double2 gv{0, 0}; if (!D.z) gv = g2[q];          // (an explicit z makes the residual unnecessary here: one pass less)
+    double2 dv = d2[q], xv;
     xv.x = __builtin_nontemporal_load(&x[2 * q]); xv.y = __builtin_nontemporal_load(&x[2 * q + 1]);
     const double z0 = D.z ? D.z[2 * q] : prec ? gv.x * diag_at<NC>(D, 2 * q) : gv.x, z1 = D.z ? D.z[2 * q + 1] : prec ? gv.y * diag_at<NC>(D, 2 * q + 1) : gv.y;
     xv.x = fma(alpha, dv.x, xv.x); xv.y = fma(alpha, dv.y, xv.y);
@@ -363,7 +366,7 @@ template <int NC> __global__ void k_pcg_update_d_fused(PcgScalars *sc, int parit
     __builtin_nontemporal_store(xv.x, &x[2 * q]); __builtin_nontemporal_store(xv.y, &x[2 * q + 1]); d2[q] = dv;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = n - 1; const double gi = g[i], z = D.z ? D.z[i] : prec ? gi * diag_at<NC>(D, i) : gi, di = d[i];
+    const int64_t i = n - 1; const double gi = D.z ? 0.0 : g[i], z = D.z ? D.z[i] : prec ? gi * diag_at<NC>(D, i) : gi, di = d[i];
     x[i] = fma(alpha, di, x[i]); d[i] = fma(beta, di, -z);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->gh2[parity ^ 1] = gz; }
@@ -543,7 +546,7 @@ void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red, double 
 }
 void pcg_update_g_fused(hipStream_t s, PcgScalars *sc, int parity, double *g, const double *h, const DiagVec &dv, int prec, int64_t n, int64_t n_owned,
                         const double *partials_dh, const double *red, double *partials_out) {
-  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, dv.z};
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, dv.z, dv.z1_out, dv.z1_scale};
   switch (diag_nc(dv, n)) {
     case 2: hipLaunchKernelGGL(k_pcg_update_g_fused<2>, reduce_grid(n), kBlock, 0, s, sc, parity, g, h, D, prec, n, n_owned, partials_dh, red, partials_out); break;
     case 3: hipLaunchKernelGGL(k_pcg_update_g_fused<3>, reduce_grid(n), kBlock, 0, s, sc, parity, g, h, D, prec, n, n_owned, partials_dh, red, partials_out); break;
