@@ -234,6 +234,8 @@ void asm_p_matrices(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64
 void asm_proj_rhs(hipStream_t s, const AsmArgs &a, const int32_t *cells, int64_t n_cells, const double *u, int n_comp, const int32_t *comps /*host*/,
                   double *const *rhs /*host array of device ptrs*/);
 
+// ---- kernels_mfg.hip: matrix-free operator on general meshes (one wave per cell, coloured scatter) ----------------
+void mfg_apply(hipStream_t s, const AsmArgs &a, const int32_t *color_cells, const std::vector<int64_t> &color_off, int64_t n_u, const double *x, double *y, bool constrained, int mode);
 // ---- kernels_mf.hip -----------------------------------------------------------------------------
 struct MfArgs { int dim, k_u; BoxDev box; const double *Ke; const uint8_t *mask; const double *diag_local; double lam, G; int mask_anywhere; const uint8_t *nodemask; const int32_t *dirichlet_dofs; int64_t n_dirichlet; };
 void mf_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, double *dot_partials = nullptr);

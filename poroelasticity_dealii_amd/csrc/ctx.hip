@@ -196,6 +196,11 @@ MfArgs mf_args(poro_ctx *c) {
 }
 // y = A_u x without forming A_u: sum-factorised sweeps where available, element-matrix gather otherwise
 void mf_operator(poro_ctx *c, const double *x, double *y, bool constrained) {
+  if (!c->box.enabled) {   // general mesh: quadrature-level cell loop; the Dirichlet rows from the constraint list as for the structured kernels
+    mfg_apply(c->stream, asm_args(c), c->color_cells.p, c->color_off, c->n_u, x, y, constrained, 0);
+    if (constrained) kron_fix_constrained(c->stream, mf_args(c), x, y, nullptr, 0);
+    return;
+  }
   if (c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) { const int slots = kron_apply(c->stream, mf_args(c), x, y, constrained, c->n_cus); if (constrained) kron_fix_constrained(c->stream, mf_args(c), x, y, nullptr, std::abs(slots)); }
   else mf_apply(c->stream, mf_args(c), x, y, constrained);
 }
@@ -212,7 +217,7 @@ bool is_u_vec(int which) { return which == PORO_VEC_U || which == PORO_VEC_RHS_U
 // by the operator kernel itself (fused), false when the caller still has to launch the dot kernel.
 bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr, bool fix_rows = true, const PcgScalars *pcg_state = nullptr) {
   bool fused = false;
-  if (mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
+  if (mode == PORO_OP_MATRIX_FREE && c->box.enabled && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
     int slots;
     if (c->timing) {   // events attached to the dispatch itself: the kernel's own duration, without the gaps to its neighbours in the stream
       Timer &t = c->timers["apply_u_matrix_free"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
@@ -222,6 +227,10 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
     // inside PCG the Dirichlet rows are inert (zero residual and direction), so what the structured kernel leaves there is never read
     fused = dot_partials != nullptr && slots > 0;   // slots < 0: too many workgroups for the partial slots, the kernel ran without the fused x.y
     if (fix_rows) { Timed tm(c, "apply_u_dirichlet_rows"); kron_fix_constrained(c->stream, mf_args(c), x, y, fused ? dot_partials : nullptr, slots > 0 ? slots : -slots); }
+  } else if (mode == PORO_OP_MATRIX_FREE && !c->box.enabled) {
+    Timed tm(c, "apply_u_matrix_free");
+    mfg_apply(c->stream, asm_args(c), c->color_cells.p, c->color_off, c->n_u, x, y, true, 0);
+    if (fix_rows) kron_fix_constrained(c->stream, mf_args(c), x, y, nullptr, 0);
   } else {
     Timed tm(c, mode == PORO_OP_MATRIX_FREE ? "apply_u_matrix_free" : "apply_u_csr");
     if (mode == PORO_OP_MATRIX_FREE) { mf_apply(c->stream, mf_args(c), x, y, true, dot_partials); fused = dot_partials != nullptr; }
@@ -692,7 +701,7 @@ void setup(poro_ctx *c, const poro_desc *d) {
   { bool inter = true;     // node-interleaved displacement numbering?
     for (int64_t i = 0; i < c->n_cells * c->ns_u && inter; ++i) { const int32_t b = d->cell_dofs_u[i * c->dim]; if (b % c->dim) inter = false; for (int k = 1; k < c->dim && inter; ++k) if (d->cell_dofs_u[i * c->dim + k] != b + k) inter = false; }
     c->interleaved_u = inter ? 1 : 0; }
-  if (c->operator_mode == PORO_OP_MATRIX_FREE && !d->box.enabled) throw Error("matrix-free operator needs a structured box mesh (poro_desc.box)");
+  if (c->operator_mode == PORO_OP_MATRIX_FREE && !d->box.enabled && d->part.n_ranks > 1) throw Error("the matrix-free operator on a general (non-box) mesh is implemented for one rank");
   if (d->box.enabled) {
     // the lexicographic numbering the structured kernels assume must be the caller's numbering (spot-checked on three cells)
     int64_t nn[3] = {1, 1, 1}, np[3] = {1, 1, 1}, ncells = 1;
@@ -739,7 +748,7 @@ void setup(poro_ctx *c, const poro_desc *d) {
     c->dir_mask.upload(m); c->dir_val.upload(v);
     // hanging-node constraints (locally refined meshes): operator-level condensation, see include/poroel_hip.h poro_constraints
     if (d->cons_u.n || d->cons_p.n) {
-      if (c->operator_mode != PORO_OP_CSR || d->box.enabled) throw Error("constraint lists need the assembled-CSR operator on a general (non-box) mesh");
+      if (d->box.enabled) throw Error("constraint lists belong to general (non-box) meshes: assembled-CSR operator or the general matrix-free one");
       if (c->comm.part.n_ranks > 1) throw Error("constraint lists are implemented for one rank");
     }
     upload_constraints(c->cons_u, d->cons_u, c->n_u, &m, "cons_u");
@@ -764,7 +773,7 @@ void setup(poro_ctx *c, const poro_desc *d) {
   if (c->operator_mode == PORO_OP_CSR) {
     std::vector<int64_t> rp, diag; std::vector<int32_t> col; build_pattern(c->n_u, c->n_cells, c->dpc_u, d->cell_dofs_u, rp, col, diag); upload_csr(c->Au, c->n_u, rp, col, diag);
     c->Au_val.alloc(c->Au.nnz);
-  } else c->Ke.alloc((size_t)c->dpc_u * c->dpc_u);
+  } else if (d->box.enabled) c->Ke.alloc((size_t)c->dpc_u * c->dpc_u);
 
   hipStream_t s = c->stream;
   const int n_sym = dim * (dim + 1) / 2;
@@ -1029,6 +1038,11 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
         for (size_t k = 0; k + 1 < c->color_off.size(); ++k)
           asm_u_matrix(s, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], c->Au.rp.p, c->Au.col.p, c->Au_val.p, c->lift_u.p);
         la_csr_diag(s, c->Au, c->Au_val.p, c->diag_u_local.p);
+      } else if (!c->box.enabled) {
+        // general mesh, matrix-free: the diagonal and the lifting -(A_full g) come from the same quadrature-level cell loop
+        mfg_apply(s, a, c->color_cells.p, c->color_off, c->n_u, nullptr, c->diag_u_local.p, false, 1);
+        mfg_apply(s, a, c->color_cells.p, c->color_off, c->n_u, c->dir_val.p, c->wh_u.p, false, 0);
+        la_fill(s, c->lift_u.p, 0.0, c->n_u); la_axpy(s, c->lift_u.p, -1.0, c->wh_u.p, c->n_u);
       } else {
         asm_u_element_matrix(s, a, 0, c->Ke.p);
         mf_diag(s, mf_args(c), c->diag_u_local.p);
@@ -1091,7 +1105,8 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
       double *rhs = vec(c, PORO_VEC_RHS_U);
       if (c->cons_u.any_inhom) {
         la_fill(s, c->wd_u.p, 0.0, c->n_u); la_cons_expand(s, c->cons_u, c->wd_u.p, true);
-        la_csr_spmv(s, c->Au, c->Au_val.p, c->wd_u.p, c->wh_u.p);
+        if (c->operator_mode == PORO_OP_CSR) la_csr_spmv(s, c->Au, c->Au_val.p, c->wd_u.p, c->wh_u.p);
+        else mf_operator(c, c->wd_u.p, c->wh_u.p, true);
         la_mask_zero(s, c->wh_u.p, c->dir_mask.p, c->n_u);
         la_axpy(s, rhs, -1.0, c->wh_u.p, c->n_u);
       }

@@ -1,0 +1,69 @@
+"""Matrix-free operator on GENERAL meshes (the kernel BASELINE.json's north_star describes: element dof indices, quadrature data and the constant
+material coefficients staged in LDS; PoroElasticDisplacementSolver.h:206-246 applied to a vector): the bundled Gmsh mesh of config 1 (read_mesh,
+PoroelasticityFSS.h:438-445) and locally refined boxes with hanging nodes, against the assembled CSR operator and the oracle."""
+import numpy as np
+import pytest
+
+import poroelasticity_dealii_amd as pk
+import oracle_py
+from common import BC_2D, DOMAIN_MSH, REF, host_material
+from test_constraints_cpu import MESHES, refined
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("deg", [1, 2])
+def test_gmsh_mesh_matrix_free_equals_assembled(deg):
+    P = pk.Problem.gmsh(DOMAIN_MSH, deg, host_material(), BC_2D)
+    A, F = pk.Context(P, 0, pk.OP_CSR), pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    O = oracle_py.Oracle(P, hoisted=True)
+    try:
+        p = REF["p_init"] * (1 + 0.2 * np.sin(0.37 * np.arange(A.n_p)))
+        for S in (A, F, O):
+            S.set(pk.VEC_P, p); S.disp_assemble_system(True)
+        x = np.sin(0.37 * np.arange(A.n_u))
+        ya, yf, yo = A.apply(pk.MAT_A_U, x), F.apply(pk.MAT_A_U, x), O.apply(pk.MAT_A_U, x)
+        assert np.abs(ya - yo).max() <= 1e-12 * np.abs(yo).max() and np.abs(yf - yo).max() <= 1e-12 * np.abs(yo).max()
+        assert np.abs(F.get(pk.VEC_DIAG_U) - A.get(pk.VEC_DIAG_U)).max() <= 1e-12 * np.abs(A.get(pk.VEC_DIAG_U)).max()
+        assert np.abs(F.get(pk.VEC_RHS_U) - O.get(pk.VEC_RHS_U)).max() <= 1e-12 * np.abs(O.get(pk.VEC_RHS_U)).max()
+        assert O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=20000)[0] == 0
+        for prec in (pk.PREC_JACOBI, pk.PREC_CHEBYSHEV):
+            F.fill(pk.VEC_U, 0.0)
+            rc, info = F.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=20000, prec=prec)
+            assert rc == 0 and np.linalg.norm(F.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+        assert not F.supports_preconditioner(0, pk.PREC_FDM)
+    finally:
+        A.close(); F.close(); O.close(); P.close()
+
+
+def test_config_1_time_step_matrix_free():
+    """BASELINE config 1 (domain.msh + input.data, Q1/Q1, one time step) with the matrix-free displacement operator: same trace and fields as the oracle"""
+    P = pk.Problem.gmsh(DOMAIN_MSH, 1, host_material(), BC_2D)
+    O = oracle_py.Oracle(P, hoisted=True)
+    try:
+        t0, _ = O.run(1, REF["p_init"], REF["dt"], max_it=5000)
+        t1, G = pk.run_problem(P, 1, REF["p_init"], REF["dt"], operator_mode=pk.OP_MATRIX_FREE, max_it=5000)
+        assert np.array_equal(t1[:, :3], t0[:, :3])
+        assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-8 * np.linalg.norm(O.get(pk.VEC_U))
+        assert np.abs(G.get(pk.VEC_P) - O.get(pk.VEC_P)).max() <= 1e-10 * np.abs(O.get(pk.VEC_P)).max()
+        G.close()
+    finally:
+        O.close(); P.close()
+
+
+@pytest.mark.parametrize("cfg", MESHES, ids=str)
+def test_hanging_node_meshes_matrix_free(cfg):
+    """locally refined boxes: the general matrix-free operator under the operator-level condensation C^T A C (poro_desc.cons_u)"""
+    P = refined(*cfg)
+    O = oracle_py.Oracle(P, hoisted=True)
+    G = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    try:
+        p = REF["p_init"] * (1 + 0.3 * np.sin(0.37 * np.arange(G.n_p)))
+        for S in (O, G):
+            S.set(pk.VEC_P, p); S.disp_assemble_system(True)
+        assert np.abs(G.get(pk.VEC_RHS_U) - O.get(pk.VEC_RHS_U)).max() <= 1e-12 * np.abs(O.get(pk.VEC_RHS_U)).max()
+        rc0, _ = O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=50000); rc1, _ = G.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=50000)
+        assert rc0 == 0 and rc1 == 0
+        assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+    finally:
+        G.close(); O.close(); P.close()
