@@ -318,9 +318,11 @@ def test_error_behaviour():
     finally:
         G.close(); P.close()
     Pm = pk.Problem.gmsh(DOMAIN_MSH, 2, material(), BC_2D)
-    with pytest.raises(RuntimeError):
-        pk.Context(Pm, 0, pk.OP_MATRIX_FREE)                # unstructured mesh cannot be matrix-free
-    Pm.close()
+    Gm = pk.Context(Pm, 0, pk.OP_MATRIX_FREE)               # unstructured meshes run the general matrix-free operator (tests/test_mfg_gpu.py) ...
+    Gm.fill(pk.VEC_P, 10e6); Gm.disp_assemble_system(True)
+    with pytest.raises(RuntimeError, match="PORO_PREC_FDM"):
+        Gm.disp_solve(prec=pk.PREC_FDM)                     # ... but not the box-only preconditioner
+    Gm.close(); Pm.close()
 
 
 @pytest.mark.parametrize("deg", [2, 1])
