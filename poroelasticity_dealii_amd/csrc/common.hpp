@@ -74,7 +74,7 @@ struct FdmDist {
 
 // block fast diagonalisation of the displacement system (kernels_fdmu.hip): per (component, direction) the transform matrices S^T (fwd) and
 // S (bwd) in MFMA fragment order and the eigenvalues (inf marks removed modes); coef[c][d] = lambda + 2G (d == c) | G
-struct FdmuDir { int n = 0; bool reg_form = false; DevBuf<double> fwd, bwd, lam; };
+struct FdmuDir { int n = 0; bool reg_form = false, split = false; int n_even = 0; DevBuf<double> fwd, bwd, lam; };
 struct FdmU { int dim = 0; int nn[3] = {1, 1, 1}; double coef[3][3] = {}; FdmuDir dir[3][3]; FdmuDir last_global[3]; bool built = false, single = false;
               int fix[3][3][2] = {};
               // slab-partitioned form: node planes of the last direction are gathered per column group by an all-to-all (as FdmDist for the Q1 systems)
@@ -261,7 +261,7 @@ void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], c
 double jacobi_scaled_lambda_max(int n, const std::vector<double> &A);
 double sym_lambda_max(int n, const std::vector<double> &A);   // largest eigenvalue of a small dense symmetric matrix
 void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::vector<double> &S, std::vector<double> &lam);
-void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single);
+void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single, bool allow_split);   // D.split tells whether the even / odd form was taken
 // stage 2: the whole application (single rank); 0 / 1: the passes of the leading directions before / after the caller's distributed last direction
 void fdmu_apply(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1, void *t2, int stage);
 void fdmu_window(hipStream_t s, double *dst, const double *src, bool to_block, int ncomp, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid,

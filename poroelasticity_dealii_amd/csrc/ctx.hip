@@ -601,20 +601,30 @@ void build_fdm_u(poro_ctx *c) {
     for (int q = 0; q < N; ++q) { F.max_own = std::max(F.max_own, ku * F.layers[q] + (q == N - 1 ? 1 : 0)); F.max_nl = std::max(F.max_nl, ku * F.layers[q] + 1); }
     const size_t blk = (size_t)dim * std::max(F.max_own, F.max_nl) * F.C;
     F.sendbuf.alloc(blk * N); F.recvbuf.alloc(blk * N); F.tz1.alloc((size_t)dim * F.ng * F.C); F.tz2.alloc((size_t)dim * F.ng * F.C);
+    F.sendbuf.zero(c->stream); F.recvbuf.zero(c->stream); F.tz1.zero(c->stream); F.tz2.zero(c->stream);
   }
-  // eigenpairs per (direction, end conditions); components with the same end conditions share the host work
+  // eigenpairs per (direction, end conditions); components with the same end conditions share the host work.  A direction takes the even / odd
+  // form (half the MFMA work) when every component has the same condition at both ends there - all components of a pass share one kernel
   for (int d = 0; d < dim; ++d) {
     std::vector<double> S[4], lam[4]; bool have[4] = {false, false, false, false};
     const bool global_dir = multi && d == last;
     const int ncell = global_dir ? n_cells_last : c->box.n[d], nnode = ku * ncell + 1;
-    for (int comp = 0; comp < dim; ++comp) {
-      const int key = F.fix[comp][d][0] * 2 + F.fix[comp][d][1];
-      if (!have[key]) { fdmu_eig_1d(ku, ncell, c->box.h[d], F.fix[comp][d][0], F.fix[comp][d][1], S[key], lam[key]); have[key] = true; }
-      if (global_dir) fdmu_upload_dir(F.last_global[comp], S[key], lam[key], nnode, false);
-      else fdmu_upload_dir(F.dir[comp][d], S[key], lam[key], nnode, F.single);
+    bool allow_split = true;
+    for (int comp = 0; comp < dim; ++comp) allow_split = allow_split && F.fix[comp][d][0] == F.fix[comp][d][1];
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      bool all_split = true;
+      for (int comp = 0; comp < dim; ++comp) {
+        const int key = F.fix[comp][d][0] * 2 + F.fix[comp][d][1];
+        if (!have[key]) { fdmu_eig_1d(ku, ncell, c->box.h[d], F.fix[comp][d][0], F.fix[comp][d][1], S[key], lam[key]); have[key] = true; }
+        FdmuDir &D = global_dir ? F.last_global[comp] : F.dir[comp][d];
+        fdmu_upload_dir(D, S[key], lam[key], nnode, global_dir ? false : F.single, allow_split);
+        all_split = all_split && D.split;
+      }
+      if (!allow_split || all_split) break;
+      allow_split = false;                       // the numerical symmetry check failed for some component: the whole direction in the full form
     }
   }
-  c->fdmu_t1.alloc(c->n_u); c->fdmu_t2.alloc(c->n_u);
+  c->fdmu_t1.alloc(c->n_u); c->fdmu_t2.alloc(c->n_u); c->fdmu_t1.zero(c->stream); c->fdmu_t2.zero(c->stream);   // (only finite values ever live in the scratch arrays)
   if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
   F.built = true;
 }

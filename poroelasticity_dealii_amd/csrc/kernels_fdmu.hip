@@ -50,6 +50,9 @@ struct FdmuPass {
   // fused scaling (last direction): D(m, line) /= kd * lam_d[m] + k0 * lam0[i] + k1 * lam1[j], (i, j) = grid position of the line
   int fused; int n0; int64_t col0, col_total; double kd[3], k0[3], k1[3];
   int reg_form;         // 1: register-panel kernel (T1 / T2 point at the chunked fragment order of k_fdmu_reg)
+  int split;            // 1: even / odd form (k_fdmu_split): every component's 1D eigenvectors are symmetric or antisymmetric about the line's centre
+  int split_dir;        // split, not fused: 0 forward (nodes -> modes), 1 backward
+  int n_even[3];        // split: even modes per component (mode order along the line: even modes first, then the odd ones)
   const void *T1[3], *T2[3];             // per component: transform matrices in MFMA fragment order [MT][KK][64]
   const double *lam_d[3], *lam0[3], *lam1[3];
 };
@@ -306,6 +309,158 @@ k_fdmu_reg(FdmuPass P, const double *__restrict__ in, double *__restrict__ out) 
   }
 }
 
+// ---- even / odd form ---------------------------------------------------------------------------------------------------------------
+// On a uniform mesh with the same end condition at both ends the 1D matrices are persymmetric, so every eigenvector is symmetric or
+// antisymmetric about the centre of the line.  With e_k = x_k + x_{n-1-k}, o_k = x_k - x_{n-1-k} (k in the lower half, the centre node kept as
+// it is) the forward transform splits into two half-size products (even modes from e, odd modes from o) and the backward transform into two
+// half-size products followed by x_k = a_k + b_k, x_{n-1-k} = a_k - b_k: HALF the MFMA work of the full transform.  A lane loads point
+// 4 kk + kq of its line AND its mirror image, so the butterflies stay inside the lane; the two products of a pass run as the two MFMAs fed by
+// one 16-byte LDS read (tile pair p = even tile p, odd tile p) and share the chunked streaming of k_fdmu_reg.  Modes are stored along the line
+// with the even ones first; the eigenvalue arrays are permuted to match.  MODE 0: forward, 1: backward, 2: forward + scaling + backward.
+template <int NCH> struct SplitGeom { static constexpr int P = NCH, KKP = 4 * NCH, CHUNK = 4 * NCH * 128; };
+
+template <int NCH, int MODE>
+__global__ void __launch_bounds__(kThreads, 2)
+k_fdmu_split(FdmuPass P, const double *__restrict__ in, double *__restrict__ out) {
+  typedef SplitGeom<NCH> Gm;
+  constexpr int kAhead = NCH < 2 ? NCH : 2;
+  __shared__ double LT[2][Gm::CHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = blockIdx.y, j = lane & 15, kq = lane >> 4;
+  const int64_t n = (int64_t)blockIdx.x * 64 + w * 16 + j;
+  const bool valid = n < P.n_lines;
+  const int64_t nc = valid ? n : P.n_lines - 1;
+  const int64_t lb = P.SI == 1 ? nc * P.nK : line_base(P, nc);
+  const int64_t in_stride = P.in_interleaved ? P.SI * P.ncomp : P.SI, out_stride = P.out_interleaved ? P.SI * P.ncomp : P.SI;
+  const double *in_lane = in + (P.in_interleaved ? lb * P.ncomp + c : (int64_t)c * P.comp_stride + lb);
+  double *out_lane = out + (P.out_interleaved ? lb * P.ncomp + c : (int64_t)c * P.comp_stride + lb);
+  const int nn = P.nK, h = (nn + 1) / 2, ne = P.n_even[c], k_last = nn - 1;
+  const int KK = (h + 3) / 4;
+
+  // first operand pair: forward = (e, o) from a point and its mirror image; backward = (even, odd) coefficient groups
+  double b0[Gm::KKP], b1[Gm::KKP];
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = 4 * ch + u, k = 4 * kk + kq;
+      if (MODE == 1) {
+        b0[kk] = in_lane[(int64_t)min(k, k_last) * in_stride];
+        b1[kk] = in_lane[(int64_t)min(ne + k, k_last) * in_stride];
+      } else {
+        const int kc = min(k, h - 1), km = k_last - kc;
+        const double lo = in_lane[(int64_t)kc * in_stride], hi = in_lane[(int64_t)km * in_stride];
+        b0[kk] = km == kc ? lo : lo + hi;       // the centre node of an odd line is its own mirror image
+        b1[kk] = lo - hi;
+      }
+    }
+  };
+#pragma unroll
+  for (int ch = 0; ch < kAhead; ++ch) load_chunk(ch);
+
+  v4d acc[2 * Gm::P];
+  auto gemm = [&](const double *__restrict__ Tg, double (&be)[Gm::KKP], double (&bo)[Gm::KKP], const bool stream_b) {
+#pragma unroll
+    for (int t = 0; t < 2 * Gm::P; ++t) acc[t] = v4d{0, 0, 0, 0};
+    constexpr int PER = Gm::CHUNK / 2 / kThreads;
+    double2 stage[PER > 0 ? PER : 1];
+    const double2 *src = reinterpret_cast<const double2 *>(Tg);
+    for (int i = tid; i < Gm::CHUNK / 2; i += kThreads) reinterpret_cast<double2 *>(LT[0])[i] = src[i];
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (ch + 1 < NCH) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) stage[i] = src[(int64_t)(ch + 1) * (Gm::CHUNK / 2) + tid + i * kThreads];
+      }
+      if (stream_b && ch + kAhead < NCH) load_chunk(ch + kAhead);
+      const double2 *La = reinterpret_cast<const double2 *>(LT[ch & 1]) + lane;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = 4 * ch + u;
+        if (ch + 1 < NCH || u == 0 || kk < KK) {
+#pragma unroll
+          for (int p = 0; p < Gm::P; ++p) {
+            const double2 a = La[(u * Gm::P + p) * 64];
+            acc[2 * p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, be[kk], acc[2 * p], 0, 0, 0);
+            acc[2 * p + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bo[kk], acc[2 * p + 1], 0, 0, 0);
+          }
+        }
+      }
+      if (ch + 1 < NCH) {
+        if constexpr (PER > 0) {
+#pragma unroll
+          for (int i = 0; i < PER; ++i) reinterpret_cast<double2 *>(LT[(ch + 1) & 1])[tid + i * kThreads] = stage[i];
+        } else {
+          for (int i = tid; i < Gm::CHUNK / 2; i += kThreads) reinterpret_cast<double2 *>(LT[(ch + 1) & 1])[i] = src[(int64_t)(ch + 1) * (Gm::CHUNK / 2) + i];
+        }
+      }
+      __syncthreads();
+    }
+  };
+
+  gemm(reinterpret_cast<const double *>(P.T1[c]), b0, b1, true);
+  if constexpr (MODE == 2) {
+    double base = 0;
+    const int64_t col = min(P.col0 + nc, P.col_total - 1);
+    if (P.lam1[c]) { const int64_t jj = col / P.n0; base = P.k0[c] * P.lam0[c][col - jj * P.n0] + P.k1[c] * P.lam1[c][jj]; }
+    else if (P.lam0[c]) base = P.k0[c] * P.lam0[c][col];
+    double c0[Gm::KKP], c1[Gm::KKP];
+    const double *lam_lane = P.lam_d[c]; const double kdc = P.kd[c];
+#pragma unroll
+    for (int p = 0; p < Gm::P; ++p) {       // D register (tile p, q) of this lane = B operand of k-step 4 p + q of the same parity group
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = 16 * p + kq + 4 * q;
+        const double de = fma(kdc, lam_lane[min(m, k_last)], base), dof_ = fma(kdc, lam_lane[min(ne + m, k_last)], base);
+        double re = __builtin_amdgcn_rcp(de), ro = __builtin_amdgcn_rcp(dof_);
+        re = de < 1e300 ? fma(re, fma(-de, re, 1.0), re) : 0.0; ro = dof_ < 1e300 ? fma(ro, fma(-dof_, ro, 1.0), ro) : 0.0;
+        c0[4 * p + q] = m < ne ? acc[2 * p][q] * re : 0.0;
+        c1[4 * p + q] = ne + m < nn ? acc[2 * p + 1][q] * ro : 0.0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    gemm(reinterpret_cast<const double *>(P.T2[c]), c0, c1, false);
+  }
+  if (!valid) return;
+  if constexpr (MODE == 0) {                 // modes: even ones at m, odd ones behind them; slots behind the last mode get the zeros of the padded rows
+#pragma unroll
+    for (int p = 0; p < Gm::P; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = 16 * p + kq + 4 * q;
+        if (m < ne) out_lane[(int64_t)m * out_stride] = acc[2 * p][q];
+        if (ne + m < nn) out_lane[(int64_t)(ne + m) * out_stride] = acc[2 * p + 1][q];
+      }
+  } else {                                   // nodes: x_k = a + b, x_{n-1-k} = a - b
+#pragma unroll
+    for (int p = 0; p < Gm::P; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 16 * p + kq + 4 * q;
+        if (k >= h) continue;
+        const double a = acc[2 * p][q], b = acc[2 * p + 1][q];
+        const int km = k_last - k;
+        out_lane[(int64_t)k * out_stride] = km == k ? a : a + b;
+        if (km != k) out_lane[(int64_t)km * out_stride] = a - b;
+      }
+  }
+}
+
+inline int split_nch(int nK) { const int need = ((nK + 1) / 2 + 15) / 16; for (int v : {1, 2, 3, 4, 5}) if (need <= v) return v; return 0; }
+
+void launch_split(hipStream_t s, const FdmuPass &P, const double *in, double *out) {
+  const dim3 grid((unsigned)((P.n_lines + 63) / 64), (unsigned)P.ncomp);
+  const int mode = P.fused ? 2 : P.split_dir;
+  switch (split_nch(P.nK) * 4 + mode) {
+#define PORO_SPLIT_CASE(N) case 4 * N: hipLaunchKernelGGL((k_fdmu_split<N, 0>), grid, dim3(kThreads), 0, s, P, in, out); break; \
+                           case 4 * N + 1: hipLaunchKernelGGL((k_fdmu_split<N, 1>), grid, dim3(kThreads), 0, s, P, in, out); break; \
+                           case 4 * N + 2: hipLaunchKernelGGL((k_fdmu_split<N, 2>), grid, dim3(kThreads), 0, s, P, in, out); break;
+    PORO_SPLIT_CASE(1) PORO_SPLIT_CASE(2) PORO_SPLIT_CASE(3) PORO_SPLIT_CASE(4) PORO_SPLIT_CASE(5)
+#undef PORO_SPLIT_CASE
+    default: throw Error("launch_split: line too long");
+  }
+}
+
 inline int reg_nch(int nK) { const int need = (nK + 15) / 16; for (int v : {1, 2, 3, 5, 7, 10}) if (need <= v) return v; return 0; }
 
 void launch_reg(hipStream_t s, const FdmuPass &P, const double *in, double *out) {
@@ -324,6 +479,7 @@ void launch_reg(hipStream_t s, const FdmuPass &P, const double *in, double *out)
 template <class TC, class TIn, class TOut>
 void launch_pass(hipStream_t s, const FdmuPass &P, const TIn *in, TOut *out) {
   if constexpr (std::is_same<TC, double>::value && std::is_same<TIn, double>::value && std::is_same<TOut, double>::value) {
+    if (P.split) { launch_split(s, P, in, out); return; }
     if (P.reg_form) { launch_reg(s, P, in, out); return; }
   }
   const int rows = std::max(P.KK * 4, P.MT * 16);
@@ -476,8 +632,43 @@ static void upload_chunked(DevBuf<double> &dst, const std::vector<double> &Tm, i
   dst.upload(f);
 }
 
-void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single) {
-  D.n = nn; D.reg_form = !single && reg_nch(nn) > 0 && !std::getenv("PORO_FDMU_LDS_FORM");
+// even / odd form: classify the eigenvectors by their symmetry about the centre, pack the half-size matrices in the chunked pair order of k_fdmu_split
+// ([chunk][k-step u][tile p][lane][2]: element 0 = even product, 1 = odd product; lane -> row 16 p + (lane & 15), column 4 (4 chunk + u) + (lane >> 4))
+static bool upload_split(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn) {
+  const int nch = split_nch(nn); if (!nch) return false;
+  const int h = (nn + 1) / 2;
+  std::vector<int> even, odd;
+  for (int m = 0; m < nn; ++m) {
+    if (!(lam[m] < 1e300)) continue;              // removed modes
+    double ds = 0, da = 0, nrm = 0;
+    for (int k = 0; k < nn; ++k) { const double a = S[(size_t)k * nn + m], b = S[(size_t)(nn - 1 - k) * nn + m]; ds += (a - b) * (a - b); da += (a + b) * (a + b); nrm += a * a; }
+    if (ds <= 1e-20 * nrm) even.push_back(m); else if (da <= 1e-20 * nrm) odd.push_back(m); else return false;
+  }
+  const int ne = (int)even.size(), no = (int)odd.size();
+  if (ne > 16 * nch || no > 16 * nch || h > 16 * nch) return false;
+  auto pack = [&](DevBuf<double> &dst, bool forward) {
+    std::vector<double> f((size_t)nch * 4 * nch * 128, 0.0);
+    for (int ch = 0; ch < nch; ++ch) for (int u = 0; u < 4; ++u) for (int p = 0; p < nch; ++p) for (int l = 0; l < 64; ++l) for (int e = 0; e < 2; ++e) {
+      const int r = 16 * p + (l & 15), cc = 4 * (4 * ch + u) + (l >> 4);
+      const std::vector<int> &grp = e ? odd : even;
+      double v = 0;
+      if (forward) { if (r < (int)grp.size() && cc < h) v = S[(size_t)cc * nn + grp[r]]; }      // rows = modes of the parity group, columns = lower-half nodes
+      else { if (r < h && cc < (int)grp.size()) v = S[(size_t)r * nn + grp[cc]]; }              // rows = lower-half nodes, columns = modes
+      f[(((size_t)(ch * 4 + u) * nch + p) * 64 + l) * 2 + e] = v;
+    }
+    dst.upload(f);
+  };
+  pack(D.fwd, true); pack(D.bwd, false);
+  std::vector<double> lp(nn, std::numeric_limits<double>::infinity());
+  for (int i = 0; i < ne; ++i) lp[i] = lam[even[i]];
+  for (int i = 0; i < no; ++i) lp[ne + i] = lam[odd[i]];
+  D.lam.upload(lp); D.n_even = ne; D.split = true;
+  return true;
+}
+
+void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single, bool allow_split) {
+  D.n = nn; D.split = false; D.n_even = 0; D.reg_form = !single && reg_nch(nn) > 0 && !std::getenv("PORO_FDMU_LDS_FORM");
+  if (D.reg_form && allow_split && !std::getenv("PORO_FDMU_NO_SPLIT") && upload_split(D, S, lam, nn)) return;
   if (D.reg_form) { upload_chunked(D.fwd, S, nn, true); upload_chunked(D.bwd, S, nn, false); D.lam.upload(lam); return; }
   if (single) { upload_fragments<float>(D.fwd, S, nn, true); upload_fragments<float>(D.bwd, S, nn, false); }
   else { upload_fragments<double>(D.fwd, S, nn, true); upload_fragments<double>(D.bwd, S, nn, false); }
@@ -496,6 +687,8 @@ template <class TC> static void fdmu_apply_t(hipStream_t s, const FdmU &F, const
     P.SI = d == 0 ? 1 : d == 1 ? nx : nx * ny; P.n_lines = nnode / P.nK; P.comp_stride = nnode; P.ncomp = dim;
     P.x_layout = d == 0 ? 1 : 0; P.ld_line = std::max(P.KK * 4, P.MT * 16) + 2;
     P.fused = fused ? 1 : 0; P.n0 = (int)nx; P.col0 = 0; P.col_total = P.n_lines; P.reg_form = F.dir[0][d].reg_form ? 1 : 0;
+    P.split = 1; P.split_dir = fwd ? 0 : 1;
+    for (int c = 0; c < dim; ++c) { P.split = P.split && F.dir[c][d].split; P.n_even[c] = F.dir[c][d].n_even; }
     for (int c = 0; c < dim; ++c) {
       const FdmuDir &D = F.dir[c][d];
       P.T1[c] = (fwd || fused) ? (const void *)D.fwd.p : (const void *)D.bwd.p; P.T2[c] = D.bwd.p;
@@ -558,7 +751,9 @@ template <class TC> static void fdmu_lines_t(hipStream_t s, const FdmU &F, const
   FdmuPass P{};
   P.nK = last_dir[0].n; P.MT = (P.nK + 15) / 16; P.KK = (P.nK + 3) / 4;
   P.SI = C; P.n_lines = C; P.comp_stride = (int64_t)P.nK * C; P.ncomp = dim; P.x_layout = 0; P.ld_line = 0;
-  P.fused = 1; P.n0 = F.nn[0]; P.col0 = col0; P.col_total = col0 + ncol_valid; P.reg_form = last_dir[0].reg_form ? 1 : 0;   // padding columns hold zeros and stay zero
+  P.fused = 1; P.n0 = F.nn[0]; P.col0 = col0; P.col_total = col0 + ncol_valid; P.reg_form = last_dir[0].reg_form ? 1 : 0;
+  P.split = 1; P.split_dir = 0;
+  for (int c = 0; c < dim; ++c) { P.split = P.split && last_dir[c].split; P.n_even[c] = last_dir[c].n_even; }   // padding columns hold zeros and stay zero
   for (int c = 0; c < dim; ++c) {
     P.T1[c] = last_dir[c].fwd.p; P.T2[c] = last_dir[c].bwd.p; P.lam_d[c] = last_dir[c].lam.p; P.kd[c] = F.coef[c][last];
     P.lam0[c] = F.dir[c][0].lam.p; P.k0[c] = F.coef[c][0];

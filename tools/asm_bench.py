@@ -12,7 +12,7 @@ for spec in sys.argv[1:]:
     G.fill(pk.VEC_P, 10e6)
     G.disp_assemble_system(True)                      # warm-up (pattern is built at context creation)
     G.timers_reset()
-    reps = 5
+    reps = 5 if n < 64 else 1
     for _ in range(reps):
         G.disp_assemble_system(True)
     G.timers_enable(False)
