@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--transient", action="store_true",
                     help="time consecutive steps of the transient (BASELINE config 5) instead of repeating time step 1: the steps then differ (the input.data well rate is tiny, "
                          "the transient dies within ~10 steps) and ms_per_step depends on the window")
-    ap.add_argument("--prec", choices=["chebyshev", "jacobi"], default="chebyshev",
+    ap.add_argument("--prec", choices=["chebyshev", "jacobi", "block_fdm"], default="chebyshev",
                     help="preconditioner of the displacement CG in the headline run: chebyshev = Chebyshev polynomial around Jacobi, on 3D boxes fused into the operator kernel "
                          "(the other one and the block fast diagonalisation are measured as well and reported under time_to_solution)")
     ap.add_argument("--cheb-degree", type=int, default=6)

@@ -80,6 +80,10 @@ def test_rccl_data_plane_single_rank(monkeypatch):
         rc, info = G.disp_solve(max_iter=200, prec=pk.PREC_FDM)
         assert rc == 0 and info.iterations <= 40
         assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+        # Chebyshev-CG through the partitioned path (elementwise recurrence after the exchange, Lanczos estimate with all-reduced dots)
+        G.fill(pk.VEC_U, 0.0)
+        rc, info = G.disp_solve(max_iter=2000, prec=pk.PREC_CHEBYSHEV)
+        assert rc == 0 and np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
         # the distributed fast-diagonalisation solve with RCCL as the communicator (1 rank: all-reduce + the self block of the all-to-all)
         assert G.supports_preconditioner(1, pk.PREC_FDM)
         for S in (O, G):
