@@ -1,4 +1,4 @@
-// Driver executable: `poro_run input.data [--mesh domain.msh] [--degree 1|2] [--matrix-free] [--ssor] [--steps N] [--output DIR] [--corrected-output] [--coupled-fss] [--incremental-strain]`.
+// Driver executable: `poro_run input.data [--mesh domain.msh] [--degree 1|2] [--matrix-free] [--ssor | --chebyshev | --block-fdm] [--steps N] [--output DIR] [--corrected-output] [--coupled-fss] [--incremental-strain]`.
 // Stands in for the reference's missing code/source/Runner.cpp (code/CMakeLists.txt:8): argv[1] is the
 // parameter file (parse_command_line.h:5-27); the mesh is create_mesh()'s colorized box refined
 // `Initial refinement level` times (PoroelasticityFSS.h:418-435) unless --mesh names a Gmsh file
@@ -28,6 +28,8 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--incremental-strain")) incremental = true;   // storage term against the previous step instead of the initial state
     else if (!std::strcmp(argv[i], "--coupled-fss")) coupled = true;    // restore get_volumetric_strain() inside the fixed-stress loop (:399)
     else if (!std::strcmp(argv[i], "--ssor")) prec = PORO_PREC_SSOR;   // the reference's PreconditionSSOR instead of Jacobi
+    else if (!std::strcmp(argv[i], "--chebyshev")) prec = PORO_PREC_CHEBYSHEV;   // polynomial preconditioner (any mesh / operator)
+    else if (!std::strcmp(argv[i], "--block-fdm")) prec = PORO_PREC_FDM;         // block fast diagonalisation (uniform boxes with face-wise Dirichlet data)
     else { std::cerr << "unknown option " << argv[i] << std::endl; return 1; }
   }
   try {

@@ -40,6 +40,13 @@ def test_default_box_with_output_and_the_reference_preconditioner(tmp_path):
     out_dir = tmp_path / "solution"; out_dir.mkdir()
     a = run(os.path.join(GOLDEN, "input.data"), "--steps", "2", "--ssor", "--output", str(out_dir))
     b = run(os.path.join(GOLDEN, "input.data"), "--steps", "2", "--matrix-free")
+    for flag in ("--chebyshev", "--block-fdm"):                                     # the fast preconditioners give the same printed trace
+        c = run(os.path.join(GOLDEN, "input.data"), "--steps", "2", "--matrix-free", flag)
+        assert re.findall(r"pressure converged; iterations: (\d+)", c) == re.findall(r"pressure converged; iterations: (\d+)", b)
+        lc = [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", c)]
+        assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(lc, [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", b)]))
+    c = run(os.path.join(GOLDEN, "input.data"), "--steps", "1", "--matrix-free", "--mesh", os.path.join(GOLDEN, "domain.msh"), "--degree", "1", "--chebyshev")   # general matrix-free operator
+    assert len(re.findall(r"pressure converged; iterations: (\d+)", c)) == 1
     pa = re.findall(r"pressure converged; iterations: (\d+)", a); pb = re.findall(r"pressure converged; iterations: (\d+)", b)
     assert pa == pb and len(pa) == 2
     la = [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", a)]; lb = [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", b)]
