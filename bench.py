@@ -265,7 +265,7 @@ def main():
     kernel_time = M["kernel_time"]
 
     # roofline of the dominant kernel (per launch, per GPU).  Chebyshev-CG on a 3D box: the structured operator with the polynomial recurrence fused into
-    # its stores (k_kron3_*_cheb: reads z_j, g, z_{j-1}, writes z_{j+1} = 32 B / DoF, + the 8d element-index bytes the structured kernels do not read);
+    # its stores (k_kron3_*_cheb: reads z_j and g, writes z_{j+1} = 24 B / DoF, + the 8d element-index bytes the structured kernels do not read);
     # otherwise the plain operator y = A_u x (16 B / DoF + index bytes).  Launches enqueued behind the finishing iteration of a solve return at once
     # (no-ops, ~2 us): their time stays in the numerator, the average is taken over the useful applications only.
     t_plain, n_plain_launched = kernel_time["apply_u_matrix_free"]
@@ -277,8 +277,8 @@ def main():
         n_cheb_useful = args.cheb_degree * (cg_total + solves) if args.cheb_degree % 2 == 0 else (args.cheb_degree + 1) * (cg_total + solves)
         n_plain_useful = cg_total + solves
         n_apply, t_apply, n_launched = n_cheb_useful, t_cheb, n_cheb_launched
-        alg_bytes = alg_plain + 16.0 * M["n_u_local"]
-        kernel_label = "k_kron3_q%d_cheb (matrix-free A_u z_j with the Chebyshev update z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 D^-1 (g - A z_j) fused into the stores)" % deg
+        alg_bytes = alg_plain + 8.0 * M["n_u_local"]
+        kernel_label = "k_kron3_q%d_cheb (matrix-free A_u z_j with the Chebyshev root-form update z_{j+1} = z_j + omega_j D^-1 (g - A z_j) fused into the stores)" % deg
     else:
         n_apply = int(work["apply_u"]) or n_plain_launched
         n_plain_useful = n_apply; t_apply, n_launched = t_plain, n_plain_launched
@@ -332,7 +332,7 @@ def main():
                                             "achieved": alg_plain / avg_plain / 1e9 if n_plain_useful and t_plain else 0.0, "frac": alg_plain / avg_plain / 1e9 / HBM_PEAK_GBS if n_plain_useful and t_plain else 0.0},
                          "note": ("kernel alone (HIP events attached to the dispatch, as rocprofv3 reports it); inside PCG the Dirichlet dofs are inert (zero residual / direction), so no row fix-up runs "
                                   "(k_kron_fix_constrained only serves poro_apply_operator: %d launches in the timed region); "
-                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells per operator application, + 16 N for the two extra streams of the fused Chebyshev update) although the "
+                                  "algorithmic bytes follow SURVEY 8d (16 N + 4 dpc n_cells per operator application, + 8 N for the extra stream g of the fused Chebyshev update) although the "
                                   "structured kernels read no index arrays (frac_without_index_bytes leaves them out); "
                                   "traffic = PMC bytes per launch from profiles/r02_pmc_traffic.json, null unless that file was measured on this kernel source") % n_fix},
             "work_per_step": {k: work[k] / args.steps for k in work},

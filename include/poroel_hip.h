@@ -172,7 +172,7 @@ enum { PORO_STOP_RHS = 0, PORO_STOP_REDUCTION = 1 };
  * triangular solves on the device; one rank, moderate sizes).
  * PORO_PREC_CHEBYSHEV (displacement system) = Chebyshev polynomial in D^-1 A of degree poly_degree around the Jacobi preconditioner: the CG iteration
  * count drops by about the degree + 1 while the operator applications of the polynomial need no dot products and, on 3D boxes, no vector kernels either
- * (the recurrence is applied inside the structured operator kernel where the product leaves the registers): fewer bytes and far fewer reductions per
+ * (the update z_{j+1} = z_j + D^-1 (g - A z_j) / r_j - roots r_j of the shifted Chebyshev polynomial - is applied inside the structured operator kernel where the product leaves the registers): fewer bytes and far fewer reductions per
  * operator application than Jacobi-CG.  lambda_max(D^-1 A) is estimated by a power iteration when the matrix is (re)built. */
 enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3, PORO_PREC_ILU0 = 4, PORO_PREC_CHEBYSHEV = 5 };
 enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };

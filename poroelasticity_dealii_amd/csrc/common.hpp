@@ -186,11 +186,10 @@ void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, dou
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag);
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n);
 void la_pointwise_mul(hipStream_t s, double *y, const double *x, int64_t n);   // y *= x
-// Chebyshev recurrence around the (inverse) Jacobi diagonal: z1 = s D^-1 g;  z_new = z_j + c1 (z_j - z_prev) + c2 D^-1 (g - A z_j) (z_new may alias z_prev;
-// z_prev == nullptr: zero); gz_partials != nullptr: block partials of g . z_new over the first n_owned entries
+// polynomial preconditioner in root form around the (inverse) Jacobi diagonal: z1 = s D^-1 g;  z_new = z_j + omega D^-1 (g - A z_j);
+// gz_partials != nullptr: block partials of g . z_new over the first n_owned entries
 void la_cheb_first(hipStream_t s, double *z, const double *g, const DiagVec &dv, double scale, int64_t n);
-void la_cheb_step(hipStream_t s, double *znew, const double *zj, const double *zprev, const double *g, const double *Az, const DiagVec &dv, double c1, double c2, int64_t n,
-                  int64_t n_owned, double *gz_partials);
+void la_cheb_step(hipStream_t s, double *znew, const double *zj, const double *g, const double *Az, const DiagVec &dv, double omega, int64_t n, int64_t n_owned, double *gz_partials);
 // x[dof_i] = sum_k w_k x[master_k] (+ inhomogeneity_i): ConstraintMatrix::distribute; with_inhom = false inside the Krylov iteration
 void la_cons_expand(hipStream_t s, const ConsDev &C, double *x, bool with_inhom);
 // y <- C^T y: y[master] += sum w y[dof_i], then y[dof_i] = 0 (ConstraintMatrix::condense of a vector)
@@ -244,8 +243,8 @@ void mf_diag(hipStream_t s, const MfArgs &a, double *diag);
 void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double kappa, const double *x, double *y);
 void p_residual_stencil(hipStream_t s, int dim, const BoxDev &box, double kappa, const double *t, const double *p, const double *src, double *R);
 
-// Chebyshev step fused into the structured operator's stores: z_new = z_j + c1 (z_j - z_prev) + c2 D^-1 (g - A z_j), D^-1 in dictionary form
-struct KronCheb { const double *g = nullptr, *zprev = nullptr; double *znew = nullptr; double c1 = 0, c2 = 0; const uint8_t *cls = nullptr; const double *tab = nullptr; int first = 0 /* z_prev = 0 */; };
+// polynomial-preconditioner step fused into the structured operator's stores: z_new = z_j + omega D^-1 (g - A z_j), D^-1 in dictionary form; z_new != z_j
+struct KronCheb { const double *g = nullptr; double *znew = nullptr; double omega = 0; const uint8_t *cls = nullptr; const double *tab = nullptr; };
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);
 void kron_prepare_device();   // per-device function attributes (dynamic LDS opt-in) of the structured kernels; call after hipSetDevice

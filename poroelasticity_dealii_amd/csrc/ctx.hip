@@ -1188,7 +1188,14 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         int nmax = 1; for (int k = 0; k < c->dim; ++k) nmax = std::max(nmax, c->box.enabled ? c->box.n[k] : (int)std::lround(std::pow((double)c->n_cells, 1.0 / c->dim)));
         ratio = std::min(400.0, std::max(10.0, (c->k_u == 2 ? 0.2 : 0.05) * nmax * nmax));
       }
-      const double lmax = c->cheb_lmax, lmin = lmax / ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+      // root form: the residual polynomial of degree m + 1 is prod_i (1 - lambda / r_i) with the roots r_i of the Chebyshev polynomial shifted to
+      // [lambda_max / ratio, lambda_max]; z_1 = D^-1 g / r_0, z_{j+1} = z_j + D^-1 (g - A z_j) / r_j.  Same polynomial as the three-term recurrence
+      // (identical CG iteration counts in the prototype for every ordering at these degrees) with ONE extra stream per step (g) instead of two;
+      // the roots are taken alternately from both ends so that no run of small roots inflates the intermediate iterates
+      const double lmax = c->cheb_lmax, lmin = lmax / ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+      std::vector<double> roots;
+      { std::vector<double> r(m + 1); for (int i = 0; i <= m; ++i) r[i] = theta - delta * std::cos(3.14159265358979323846 * (2 * i + 1) / (2.0 * (m + 1)));
+        int lo = 0, hi = m; while (lo <= hi) { roots.push_back(r[hi--]); if (lo <= hi) roots.push_back(r[lo++]); } }
       if (!c->cheb_z.p) { c->cheb_z.alloc(c->n_u); c->cheb_z.zero(c->stream); c->cheb_t.alloc(c->n_u); c->cheb_t.zero(c->stream); }
       if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
       const bool fuse = mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && c->dim == 3 && kron_supported(c->dim, c->k_u) && !c->comm.multi() && c->diag_u_cls.p && !c->cons_u.n &&
@@ -1198,17 +1205,16 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         Timed tm(c, "precondition_u_chebyshev");
         hipStream_t s = c->stream;
         double *X[2] = {(m % 2 == 0) ? z : c->cheb_z.p, (m % 2 == 0) ? c->cheb_z.p : z};   // z_{j+1} lands in X[j & 1]; the last one (j = m) in z
-        if (!gz_partials) la_cheb_first(s, X[0], g, dj, 1.0 / theta, c->n_u);   // inside the iteration z_1 = D^-1 g / theta was stored by the residual update (DiagVec::z1_out)
-        double rho = 1.0 / sigma; bool dot_done = false;
+        if (!gz_partials) la_cheb_first(s, X[0], g, dj, 1.0 / roots[0], c->n_u);   // inside the iteration z_1 = D^-1 g / r_0 was stored by the residual update (DiagVec::z1_out)
+        bool dot_done = false;
         // (the device-side "solve finished" flag may only gate launches inside the iteration: before pcg_scalars_start it still holds the previous solve's state)
         const PcgScalars *pstate = gz_partials ? c->scal.p : nullptr;
         for (int j = 1; j <= m; ++j) {
-          const double rho_new = 1.0 / (2.0 * sigma - rho), c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
-          rho = rho_new;
+          const double omega = 1.0 / roots[j];
           double *zj = X[(j - 1) & 1], *zn = X[j & 1];
           const bool last = j == m;
           if (fuse) {
-            KronCheb kc; kc.g = g; kc.zprev = zn; kc.znew = zn; kc.c1 = c1; kc.c2 = c2; kc.cls = c->diag_u_cls.p; kc.tab = c->diag_u_tab.p; kc.first = j == 1 ? 1 : 0;
+            KronCheb kc; kc.g = g; kc.znew = zn; kc.omega = omega; kc.cls = c->diag_u_cls.p; kc.tab = c->diag_u_tab.p;
             double *dp = (last && gz_partials) ? gz_partials : nullptr;
             if (dp) PORO_HIP(hipMemsetAsync(dp, 0, kMaxPartials * sizeof(double), s));
             int slots;
@@ -1218,7 +1224,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
             if (dp && slots > 0) dot_done = true;
           } else {
             apply(zj, c->cheb_t.p, nullptr);
-            la_cheb_step(s, zn, zj, j == 1 ? nullptr : zn, g, c->cheb_t.p, dj, c1, c2, c->n_u, n_own, (last && gz_partials) ? gz_partials : nullptr);
+            la_cheb_step(s, zn, zj, g, c->cheb_t.p, dj, omega, c->n_u, n_own, (last && gz_partials) ? gz_partials : nullptr);
             if (last && gz_partials) dot_done = true;
           }
           ++c->cheb_applies;
@@ -1226,7 +1232,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         return dot_done;
       };
       DiagVec dz = dj; dz.z = c->wz_u.p;
-      dz.z1_out = (m % 2 == 0) ? c->wz_u.p : c->cheb_z.p; dz.z1_scale = 1.0 / theta;
+      dz.z1_out = (m % 2 == 0) ? c->wz_u.p : c->cheb_z.p; dz.z1_scale = 1.0 / roots[0];
       const int64_t applies0 = c->cheb_applies;
       const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_cheb_u);
       // useful operator applications: one per CG iteration + the initial residual, and m per preconditioner call (one call per iteration + the first direction)

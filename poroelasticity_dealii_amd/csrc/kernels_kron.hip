@@ -188,15 +188,17 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
     };
     const double (&xc)[3] = oddz ? W3 : W2;            // this plane's (masked) input values, for the fused x.y
     const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
-    // CHEB: x is the Chebyshev iterate z_j; instead of A z_j the kernel stores z_{j+1} = z_j + c1 (z_j - z_{j-1}) + c2 D^-1 (g - A z_j) (z_{j+1} may
-    // overwrite z_{j-1}: every entry is read and written by its own thread only) and accumulates g . z_{j+1}.  Dirichlet dofs have D^-1 = 0 and z = 0.
+    // CHEB: x is the iterate z_j of the polynomial preconditioner in root form; instead of A z_j the kernel stores z_{j+1} = z_j + omega_j D^-1 (g - A z_j)
+    // (omega_j = reciprocal of a root of the shifted Chebyshev polynomial; z_{j+1} goes to the other buffer of a ping-pong pair because neighbouring
+    // tiles still read z_j) and accumulates g . z_{j+1}.  One extra read stream (g) instead of the two of the three-term recurrence.  Dirichlet dofs have
+    // D^-1 = 0 and z = 0.
     const double *ctab = nullptr;
     if constexpr (CHEB) ctab = a.cheb.tab + (out ? 3u * a.cheb.cls[d0 / 3] : 0u);
     auto emit = [&](int c, double v) {
       if (!out) return;
       if constexpr (CHEB) {
-        const double gi = a.cheb.g[d0 + c], zp = a.cheb.first ? 0.0 : a.cheb.zprev[d0 + c];
-        const double zn = fma(a.cheb.c2 * ctab[c], gi - v, fma(a.cheb.c1, xc[c] - zp, xc[c]));
+        const double gi = a.cheb.g[d0 + c];
+        const double zn = fma(a.cheb.omega * ctab[c], gi - v, xc[c]);
         a.cheb.znew[d0 + c] = zn; dot_acc = fma(gi, zn, dot_acc);
       } else { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); }   // Dirichlet rows: see the header
     };
@@ -284,7 +286,7 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   if (tile < a.nA) kron_tile<64, false>(a, x, y, L, 60 * (tile / (a.nzc * a.nty64)) - 2, (tile / a.nzc) % a.nty64, tile % a.nzc);
   else { const int t = tile - a.nA; kron_tile<32, false>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
 }
-// the same sweep with the Chebyshev recurrence fused into the stores (polynomial preconditioner of the displacement CG: no vector kernels and no
+// the same sweep with the Chebyshev (root form) update fused into the stores (polynomial preconditioner of the displacement CG: no vector kernels and no
 // reductions between the operator applications of one preconditioner call)
 __global__ void __launch_bounds__(1024)
 k_kron3_q2_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
@@ -377,8 +379,8 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
     auto emit = [&](int c, double v) {
       if (!out) return;
       if constexpr (CHEB) {      // see kron_tile
-        const double gi = a.cheb.g[d0 + c], zp = a.cheb.first ? 0.0 : a.cheb.zprev[d0 + c];
-        const double zn = fma(a.cheb.c2 * ctab[c], gi - v, fma(a.cheb.c1, xc[c] - zp, xc[c]));
+        const double gi = a.cheb.g[d0 + c];
+        const double zn = fma(a.cheb.omega * ctab[c], gi - v, xc[c]);
         a.cheb.znew[d0 + c] = zn; dot_acc = fma(gi, zn, dot_acc);
       } else { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); }
     };

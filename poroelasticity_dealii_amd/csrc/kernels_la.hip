@@ -374,13 +374,12 @@ template <int NC> __global__ void k_pcg_update_d_fused(PcgScalars *sc, int parit
 template <int NC> __global__ void k_cheb_first(double *z, const double *g, DiagRef D, double scale, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) z[i] = scale * diag_at<NC>(D, i) * g[i];
 }
-template <int NC> __global__ void k_cheb_step(double *znew, const double *zj, const double *zprev, const double *g, const double *Az, DiagRef D, double c1, double c2, int64_t n,
-                                              int64_t n_owned, double *gz_partials) {
+template <int NC> __global__ void k_cheb_step(double *znew, const double *zj, const double *g, const double *Az, DiagRef D, double omega, int64_t n, int64_t n_owned, double *gz_partials) {
   __shared__ double sh[4];
   double acc = 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double z = zj[i], zp = zprev ? zprev[i] : 0.0, gi = g[i];
-    const double zn = fma(c2 * diag_at<NC>(D, i), gi - Az[i], fma(c1, z - zp, z));
+    const double gi = g[i];
+    const double zn = fma(omega * diag_at<NC>(D, i), gi - Az[i], zj[i]);
     znew[i] = zn;
     if (i < n_owned) acc = fma(gi, zn, acc);
   }
@@ -514,13 +513,12 @@ void la_cheb_first(hipStream_t s, double *z, const double *g, const DiagVec &dv,
     default: hipLaunchKernelGGL(k_cheb_first<0>, grid_for(n), kBlock, 0, s, z, g, D, scale, n);
   }
 }
-void la_cheb_step(hipStream_t s, double *znew, const double *zj, const double *zprev, const double *g, const double *Az, const DiagVec &dv, double c1, double c2, int64_t n,
-                  int64_t n_owned, double *gz_partials) {
+void la_cheb_step(hipStream_t s, double *znew, const double *zj, const double *g, const double *Az, const DiagVec &dv, double omega, int64_t n, int64_t n_owned, double *gz_partials) {
   const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, nullptr};
   switch (diag_nc(dv, n)) {
-    case 2: hipLaunchKernelGGL(k_cheb_step<2>, reduce_grid(n), kBlock, 0, s, znew, zj, zprev, g, Az, D, c1, c2, n, n_owned, gz_partials); break;
-    case 3: hipLaunchKernelGGL(k_cheb_step<3>, reduce_grid(n), kBlock, 0, s, znew, zj, zprev, g, Az, D, c1, c2, n, n_owned, gz_partials); break;
-    default: hipLaunchKernelGGL(k_cheb_step<0>, reduce_grid(n), kBlock, 0, s, znew, zj, zprev, g, Az, D, c1, c2, n, n_owned, gz_partials);
+    case 2: hipLaunchKernelGGL(k_cheb_step<2>, reduce_grid(n), kBlock, 0, s, znew, zj, g, Az, D, omega, n, n_owned, gz_partials); break;
+    case 3: hipLaunchKernelGGL(k_cheb_step<3>, reduce_grid(n), kBlock, 0, s, znew, zj, g, Az, D, omega, n, n_owned, gz_partials); break;
+    default: hipLaunchKernelGGL(k_cheb_step<0>, reduce_grid(n), kBlock, 0, s, znew, zj, g, Az, D, omega, n, n_owned, gz_partials);
   }
 }
 void pcg_init_residual(hipStream_t s, double *g, const double *Ax, const double *b, const uint8_t *inert, int64_t n) {
