@@ -74,7 +74,7 @@ struct FdmDist {
 
 // block fast diagonalisation of the displacement system (kernels_fdmu.hip): per (component, direction) the transform matrices S^T (fwd) and
 // S (bwd) in MFMA fragment order and the eigenvalues (inf marks removed modes); coef[c][d] = lambda + 2G (d == c) | G
-struct FdmuDir { int n = 0; bool reg_form = false, split = false; int n_even = 0; DevBuf<double> fwd, bwd, lam; };
+struct FdmuDir { int n = 0; bool reg_form = false, split = false, blk = false; int n_even = 0; int blk_kk[2] = {0, 0}, blk_nch[2] = {0, 0}, blk_mb[2] = {0, 0} /* [forward, backward] */; DevBuf<double> fwd, bwd, lam; };
 struct FdmU { int dim = 0; int nn[3] = {1, 1, 1}; double coef[3][3] = {}; FdmuDir dir[3][3]; FdmuDir last_global[3]; bool built = false, single = false;
               int fix[3][3][2] = {};
               // slab-partitioned form: node planes of the last direction are gathered per column group by an all-to-all (as FdmDist for the Q1 systems)

@@ -522,7 +522,7 @@ void analyse_fdm_u(poro_ctx *c) {
   FdmU &F = c->fdm_u;
   if (!c->box.enabled || !c->interleaved_u) why = "needs a uniform box with node-interleaved displacement dofs";
   else {
-    for (int d = 0; d < dim; ++d) if (nn[d] > 320) why = "more than 320 nodes per grid line";
+    for (int d = 0; d < dim; ++d) if (nn[d] > 4096) why = "more than 4096 nodes per grid line";
   }
   if (why.empty()) {
     const std::vector<uint8_t> &nm = c->h_node_mask;
@@ -594,7 +594,7 @@ void build_fdm_u(poro_ctx *c) {
     F.layers.resize(N); F.off.resize(N); int acc = 0;
     for (int q = 0; q < N; ++q) { F.layers[q] = (int)std::lround(lay[q]); F.off[q] = ku * acc; acc += F.layers[q]; }
     n_cells_last = acc; F.ng = ku * acc + 1;
-    if (F.ng > 320) throw Error("PORO_PREC_FDM (displacement): more than 320 nodes per global grid line");
+    if (F.ng > 4096) throw Error("PORO_PREC_FDM (displacement): more than 4096 nodes per global grid line");
     F.ncol_total = 1; for (int d = 0; d < last; ++d) F.ncol_total *= F.nn[d];
     F.C = (F.ncol_total + N - 1) / N;
     F.max_own = 0; F.max_nl = 0;

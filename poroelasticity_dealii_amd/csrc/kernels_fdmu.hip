@@ -53,6 +53,9 @@ struct FdmuPass {
   int split;            // 1: even / odd form (k_fdmu_split): every component's 1D eigenvectors are symmetric or antisymmetric about the line's centre
   int split_dir;        // split, not fused: 0 forward (nodes -> modes), 1 backward
   int n_even[3];        // split: even modes per component (mode order along the line: even modes first, then the odd ones)
+  int blk;              // split form for lines of more than 160 points (k_fdmu_blk): the output rows are produced in blocks of 80 per parity, the transform matrix is
+  int blk_kk, blk_nch, blk_mb;   //   packed [row block][chunk]...; k-steps, chunks per row block and row blocks of THIS pass (forward / backward differ)
+  int scale_on_load;    // blk backward pass of the last direction: the coefficients are divided by the eigenvalue sums as they are loaded
   const void *T1[3], *T2[3];             // per component: transform matrices in MFMA fragment order [MT][KK][64]
   const double *lam_d[3], *lam0[3], *lam1[3];
 };
@@ -446,10 +449,125 @@ k_fdmu_split(FdmuPass P, const double *__restrict__ in, double *__restrict__ out
   }
 }
 
+// ---- even / odd form for long lines (> 160 points: 2D config 2 has 673, a 128^3 Q2 box 257) ------------------------------------------------
+// Same arithmetic as k_fdmu_split, but the 2 x 5 accumulator tiles cover only 80 output rows per parity: the rows are produced block by block, each block
+// streaming ALL k-steps of its slice of the transform matrix through LDS while the data fragments are re-read (L2) and, for the forward direction,
+// butterflied again.  Loops are runtime loops (the line length is arbitrary), the data fragments of the next chunk are requested one chunk ahead.
+// MODE 0 forward, 1 backward (optionally dividing the coefficients by the eigenvalue sums on load: the last direction, whose forward / backward
+// pair cannot be chained through registers at this length).
+template <int MODE>
+__global__ void __launch_bounds__(kThreads, 2)
+k_fdmu_blk(FdmuPass P, const double *__restrict__ in, double *__restrict__ out) {
+  constexpr int PP = 5, CHUNK = 4 * PP * 128, PER = CHUNK / 2 / kThreads;
+  __shared__ double LT[2][CHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = blockIdx.y, j = lane & 15, kq = lane >> 4;
+  const int64_t n = (int64_t)blockIdx.x * 64 + w * 16 + j;
+  const bool valid = n < P.n_lines;
+  const int64_t nc = valid ? n : P.n_lines - 1;
+  const int64_t lb = P.SI == 1 ? nc * P.nK : line_base(P, nc);
+  const int64_t in_stride = P.in_interleaved ? P.SI * P.ncomp : P.SI, out_stride = P.out_interleaved ? P.SI * P.ncomp : P.SI;
+  const double *in_lane = in + (P.in_interleaved ? lb * P.ncomp + c : (int64_t)c * P.comp_stride + lb);
+  double *out_lane = out + (P.out_interleaved ? lb * P.ncomp + c : (int64_t)c * P.comp_stride + lb);
+  const int nn = P.nK, h = (nn + 1) / 2, ne = P.n_even[c], k_last = nn - 1;
+  const int NCHK = P.blk_nch, KK = P.blk_kk;
+  double base = 0; const double *lam_lane = nullptr; double kdc = 0;
+  if (MODE == 1 && P.scale_on_load) {
+    const int64_t col = min(P.col0 + nc, P.col_total - 1);
+    if (P.lam1[c]) { const int64_t jj = col / P.n0; base = P.k0[c] * P.lam0[c][col - jj * P.n0] + P.k1[c] * P.lam1[c][jj]; }
+    else if (P.lam0[c]) base = P.k0[c] * P.lam0[c][col];
+    lam_lane = P.lam_d[c]; kdc = P.kd[c];
+  }
+  auto load_chunk = [&](int ch, double (&b0)[4], double (&b1)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 4 * (4 * ch + u) + kq;
+      if (MODE == 1) {
+        const int ie = min(k, k_last), io = min(ne + k, k_last);
+        double ve = in_lane[(int64_t)ie * in_stride], vo = in_lane[(int64_t)io * in_stride];
+        if (lam_lane) {
+          const double de = fma(kdc, lam_lane[ie], base), dd = fma(kdc, lam_lane[io], base);
+          double re = __builtin_amdgcn_rcp(de), ro = __builtin_amdgcn_rcp(dd);
+          re = de < 1e300 ? fma(re, fma(-de, re, 1.0), re) : 0.0; ro = dd < 1e300 ? fma(ro, fma(-dd, ro, 1.0), ro) : 0.0;
+          ve *= re; vo *= ro;
+        }
+        b0[u] = ve; b1[u] = vo;
+      } else {
+        const int kc = min(k, h - 1), km = k_last - kc;
+        const double lo = in_lane[(int64_t)kc * in_stride], hi = in_lane[(int64_t)km * in_stride];
+        b0[u] = km == kc ? lo : lo + hi; b1[u] = lo - hi;
+      }
+    }
+  };
+  for (int mb = 0; mb < P.blk_mb; ++mb) {
+    v4d acc[2 * PP];
+#pragma unroll
+    for (int t = 0; t < 2 * PP; ++t) acc[t] = v4d{0, 0, 0, 0};
+    const double2 *src = reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(P.T1[c]) + (int64_t)mb * NCHK * CHUNK);
+    double2 stage[PER];
+    double b0[4], b1[4], n0[4], n1[4];
+    __syncthreads();                                        // the previous row block has finished with both LDS buffers
+#pragma unroll
+    for (int i = 0; i < PER; ++i) reinterpret_cast<double2 *>(LT[0])[tid + i * kThreads] = src[tid + i * kThreads];
+    load_chunk(0, b0, b1);
+    __syncthreads();
+    for (int ch = 0; ch < NCHK; ++ch) {
+      const bool more = ch + 1 < NCHK;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) stage[i] = src[(int64_t)(ch + 1) * (CHUNK / 2) + tid + i * kThreads];
+        load_chunk(ch + 1, n0, n1);
+      }
+      const double2 *La = reinterpret_cast<const double2 *>(LT[ch & 1]) + lane;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (4 * ch + u < KK) {
+#pragma unroll
+          for (int p = 0; p < PP; ++p) {
+            const double2 a = La[(u * PP + p) * 64];
+            acc[2 * p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0[u], acc[2 * p], 0, 0, 0);
+            acc[2 * p + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1[u], acc[2 * p + 1], 0, 0, 0);
+          }
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) reinterpret_cast<double2 *>(LT[(ch + 1) & 1])[tid + i * kThreads] = stage[i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { b0[u] = n0[u]; b1[u] = n1[u]; }
+      }
+      __syncthreads();
+    }
+    if (valid) {
+#pragma unroll
+      for (int p = 0; p < PP; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * (PP * mb + p) + kq + 4 * q;
+          if (MODE == 0) {
+            if (r < ne) out_lane[(int64_t)r * out_stride] = acc[2 * p][q];
+            if (ne + r < nn) out_lane[(int64_t)(ne + r) * out_stride] = acc[2 * p + 1][q];
+          } else if (r < h) {
+            const double a = acc[2 * p][q], b = acc[2 * p + 1][q];
+            const int km = k_last - r;
+            out_lane[(int64_t)r * out_stride] = km == r ? a : a + b;
+            if (km != r) out_lane[(int64_t)km * out_stride] = a - b;
+          }
+        }
+    }
+  }
+}
+
 inline int split_nch(int nK) { const int need = ((nK + 1) / 2 + 15) / 16; for (int v : {1, 2, 3, 4, 5}) if (need <= v) return v; return 0; }
 
 void launch_split(hipStream_t s, const FdmuPass &P, const double *in, double *out) {
   const dim3 grid((unsigned)((P.n_lines + 63) / 64), (unsigned)P.ncomp);
+  if (P.blk) {
+    if (P.fused) throw Error("launch_split: the blocked form runs the last direction as two passes");
+    if (P.split_dir == 0) hipLaunchKernelGGL((k_fdmu_blk<0>), grid, dim3(kThreads), 0, s, P, in, out);
+    else hipLaunchKernelGGL((k_fdmu_blk<1>), grid, dim3(kThreads), 0, s, P, in, out);
+    return;
+  }
   const int mode = P.fused ? 2 : P.split_dir;
   switch (split_nch(P.nK) * 4 + mode) {
 #define PORO_SPLIT_CASE(N) case 4 * N: hipLaunchKernelGGL((k_fdmu_split<N, 0>), grid, dim3(kThreads), 0, s, P, in, out); break; \
@@ -533,6 +651,77 @@ void jacobi_eig(int n, std::vector<double> &A, std::vector<double> &V, std::vect
   w.resize(n); for (int i = 0; i < n; ++i) w[i] = A[(size_t)i * n + i];
 }
 
+// symmetric eigenproblem by Householder tridiagonalisation + implicit QL with accumulated transformations (the classical tred2 / tql2 pair):
+// O(n^3) with a small constant, for the long lines (n = 671 in BASELINE config 2) where the Jacobi sweeps above would take minutes.
+// A is overwritten; V's columns are the eigenvectors.
+void householder_ql_eig(int n, std::vector<double> &A, std::vector<double> &V, std::vector<double> &w) {
+  std::vector<double> d(n, 0.0), e(n, 0.0);
+  auto a = [&](int i, int j) -> double & { return A[(size_t)i * n + j]; };
+  for (int i = n - 1; i > 0; --i) {
+    const int l = i - 1; double h = 0, scale = 0;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale += std::fabs(a(i, k));
+      if (scale == 0.0) e[i] = a(i, l);
+      else {
+        for (int k = 0; k <= l; ++k) { a(i, k) /= scale; h += a(i, k) * a(i, k); }
+        double f = a(i, l), g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+        e[i] = scale * g; h -= f * g; a(i, l) = f - g; f = 0.0;
+        for (int j = 0; j <= l; ++j) {
+          a(j, i) = a(i, j) / h;
+          g = 0.0;
+          for (int k = 0; k <= j; ++k) g += a(j, k) * a(i, k);
+          for (int k = j + 1; k <= l; ++k) g += a(k, j) * a(i, k);
+          e[j] = g / h; f += e[j] * a(i, j);
+        }
+        const double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) {
+          f = a(i, j); e[j] = g = e[j] - hh * f;
+          for (int k = 0; k <= j; ++k) a(j, k) -= f * e[k] + g * a(i, k);
+        }
+      }
+    } else e[i] = a(i, l);
+    d[i] = h;
+  }
+  d[0] = 0.0; e[0] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const int l = i - 1;
+    if (d[i] != 0.0)
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= l; ++k) g += a(i, k) * a(k, j);
+        for (int k = 0; k <= l; ++k) a(k, j) -= g * a(k, i);
+      }
+    d[i] = a(i, i); a(i, i) = 1.0;
+    for (int j = 0; j <= l; ++j) a(j, i) = a(i, j) = 0.0;
+  }
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) { const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]); if (std::fabs(e[m]) <= 1e-16 * dd) break; }
+      if (m != l) {
+        if (iter++ == 200) throw Error("householder_ql_eig: no convergence");
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]), r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+        double sn = 1.0, cs = 1.0, p = 0.0; int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = sn * e[i]; const double b = cs * e[i];
+          e[i + 1] = (r = std::hypot(f, g));
+          if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+          sn = f / r; cs = g / r; g = d[i + 1] - p;
+          r = (d[i] - g) * sn + 2.0 * cs * b;
+          d[i + 1] = g + (p = sn * r); g = cs * r - b;
+          for (int k = 0; k < n; ++k) { f = a(k, i + 1); a(k, i + 1) = sn * a(k, i) + cs * f; a(k, i) = cs * a(k, i) - sn * f; }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p; e[l] = g; e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  V = A; w = d;
+}
+
 // FE_Q(k) mass / stiffness matrices of n_cells cells of length h (dense, nn = k n_cells + 1); element matrices as in kernels_kron.hip
 void fe1d(int k, int n_cells, double h, std::vector<double> &M, std::vector<double> &K) {
   const int nn = k * n_cells + 1; M.assign((size_t)nn * nn, 0.0); K.assign((size_t)nn * nn, 0.0);
@@ -578,7 +767,8 @@ void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::ve
       C[(size_t)i * nf + row] = s / Lc[(size_t)i * nf + i];
     }
   for (int i = 0; i < nf; ++i) for (int j = i + 1; j < nf; ++j) { const double a = 0.5 * (C[(size_t)i * nf + j] + C[(size_t)j * nf + i]); C[(size_t)i * nf + j] = C[(size_t)j * nf + i] = a; }
-  std::vector<double> Q, wv; jacobi_eig(nf, C, Q, wv);
+  std::vector<double> Q, wv;
+  if (nf > 96) householder_ql_eig(nf, C, Q, wv); else jacobi_eig(nf, C, Q, wv);
   for (int j = 0; j < nf; ++j) {             // back substitution L^T s = q_j
     std::vector<double> sv(nf);
     for (int i = nf - 1; i >= 0; --i) {
@@ -635,7 +825,7 @@ static void upload_chunked(DevBuf<double> &dst, const std::vector<double> &Tm, i
 // even / odd form: classify the eigenvectors by their symmetry about the centre, pack the half-size matrices in the chunked pair order of k_fdmu_split
 // ([chunk][k-step u][tile p][lane][2]: element 0 = even product, 1 = odd product; lane -> row 16 p + (lane & 15), column 4 (4 chunk + u) + (lane >> 4))
 static bool upload_split(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn) {
-  const int nch = split_nch(nn); if (!nch) return false;
+  const int nch = split_nch(nn);
   const int h = (nn + 1) / 2;
   std::vector<int> even, odd;
   for (int m = 0; m < nn; ++m) {
@@ -645,6 +835,30 @@ static bool upload_split(FdmuDir &D, const std::vector<double> &S, const std::ve
     if (ds <= 1e-20 * nrm) even.push_back(m); else if (da <= 1e-20 * nrm) odd.push_back(m); else return false;
   }
   const int ne = (int)even.size(), no = (int)odd.size();
+  std::vector<double> lp(nn, std::numeric_limits<double>::infinity());
+  for (int i = 0; i < ne; ++i) lp[i] = lam[even[i]];
+  for (int i = 0; i < no; ++i) lp[ne + i] = lam[odd[i]];
+  if (!nch) {
+    // long lines: blocked packing of k_fdmu_blk, [row block][chunk][k-step u][tile p][lane][2] with 80 rows per parity and block
+    constexpr int PP = 5;
+    auto pack_blk = [&](DevBuf<double> &dst, bool forward, int &kk_out, int &nch_out, int &mb_out) {
+      const int rows = forward ? std::max(ne, no) : h, cols = forward ? h : std::max(ne, no);
+      const int kk = (cols + 3) / 4, nchk = (kk + 3) / 4, mb = (rows + 16 * PP - 1) / (16 * PP);
+      std::vector<double> f((size_t)mb * nchk * 4 * PP * 128, 0.0);
+      for (int b = 0; b < mb; ++b) for (int ch = 0; ch < nchk; ++ch) for (int u = 0; u < 4; ++u) for (int p = 0; p < PP; ++p) for (int l = 0; l < 64; ++l) for (int e = 0; e < 2; ++e) {
+        const int r = 16 * (PP * b + p) + (l & 15), cc = 4 * (4 * ch + u) + (l >> 4);
+        const std::vector<int> &grp = e ? odd : even;
+        double v = 0;
+        if (forward) { if (r < (int)grp.size() && cc < h) v = S[(size_t)cc * nn + grp[r]]; }
+        else { if (r < h && cc < (int)grp.size()) v = S[(size_t)r * nn + grp[cc]]; }
+        f[((((size_t)(b * nchk + ch) * 4 + u) * PP + p) * 64 + l) * 2 + e] = v;
+      }
+      dst.upload(f); kk_out = kk; nch_out = nchk; mb_out = mb;
+    };
+    pack_blk(D.fwd, true, D.blk_kk[0], D.blk_nch[0], D.blk_mb[0]); pack_blk(D.bwd, false, D.blk_kk[1], D.blk_nch[1], D.blk_mb[1]);
+    D.lam.upload(lp); D.n_even = ne; D.split = true; D.blk = true;
+    return true;
+  }
   if (ne > 16 * nch || no > 16 * nch || h > 16 * nch) return false;
   auto pack = [&](DevBuf<double> &dst, bool forward) {
     std::vector<double> f((size_t)nch * 4 * nch * 128, 0.0);
@@ -659,16 +873,14 @@ static bool upload_split(FdmuDir &D, const std::vector<double> &S, const std::ve
     dst.upload(f);
   };
   pack(D.fwd, true); pack(D.bwd, false);
-  std::vector<double> lp(nn, std::numeric_limits<double>::infinity());
-  for (int i = 0; i < ne; ++i) lp[i] = lam[even[i]];
-  for (int i = 0; i < no; ++i) lp[ne + i] = lam[odd[i]];
-  D.lam.upload(lp); D.n_even = ne; D.split = true;
+  D.lam.upload(lp); D.n_even = ne; D.split = true; D.blk = false;
   return true;
 }
 
 void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single, bool allow_split) {
-  D.n = nn; D.split = false; D.n_even = 0; D.reg_form = !single && reg_nch(nn) > 0 && !std::getenv("PORO_FDMU_LDS_FORM");
-  if (D.reg_form && allow_split && !std::getenv("PORO_FDMU_NO_SPLIT") && upload_split(D, S, lam, nn)) return;
+  D.n = nn; D.split = false; D.blk = false; D.n_even = 0; D.reg_form = !single && reg_nch(nn) > 0 && !std::getenv("PORO_FDMU_LDS_FORM");
+  if (!single && allow_split && !std::getenv("PORO_FDMU_LDS_FORM") && !std::getenv("PORO_FDMU_NO_SPLIT") && upload_split(D, S, lam, nn)) return;
+  if (nn > 320) throw Error("fast diagonalisation of the displacement system: a line of more than 320 points needs the even / odd form (the same Dirichlet condition at both ends of every direction)");
   if (D.reg_form) { upload_chunked(D.fwd, S, nn, true); upload_chunked(D.bwd, S, nn, false); D.lam.upload(lam); return; }
   if (single) { upload_fragments<float>(D.fwd, S, nn, true); upload_fragments<float>(D.bwd, S, nn, false); }
   else { upload_fragments<double>(D.fwd, S, nn, true); upload_fragments<double>(D.bwd, S, nn, false); }
@@ -678,6 +890,15 @@ void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector
 // z = blockdiag(A_cc)^-1 g.  g, z: node-interleaved vectors of the local grid nn[0] x nn[1] (x nn[2]); t1, t2: planar scratch of the same size.
 // z_lines != null (partitioned run): the last-direction pass works on whole global lines of this rank's column group, which the caller
 // gathers / scatters around it (see ctx.hip); then only the passes of the leading directions run here (stage 0: forward, 1: backward).
+// fills the pass descriptor of direction d of a grid nn[0] x nn[1] (x nn[2]) from the per-(component, direction) data `dirs[c]`
+static void fill_dir(FdmuPass &P, const FdmuDir *const dirs[3], int dim, bool fwd) {
+  P.reg_form = dirs[0]->reg_form ? 1 : 0;
+  P.split = 1; P.split_dir = fwd ? 0 : 1; P.blk = 1;
+  for (int c = 0; c < dim; ++c) { P.split = P.split && dirs[c]->split; P.blk = P.blk && dirs[c]->blk; P.n_even[c] = dirs[c]->n_even; }
+  if (!P.split) P.blk = 0;
+  if (P.blk) { const int w = fwd ? 0 : 1; P.blk_kk = dirs[0]->blk_kk[w]; P.blk_nch = dirs[0]->blk_nch[w]; P.blk_mb = dirs[0]->blk_mb[w];
+               for (int c = 1; c < dim; ++c) { P.blk_kk = std::max(P.blk_kk, dirs[c]->blk_kk[w]); } }
+}
 template <class TC> static void fdmu_apply_t(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1v, void *t2v, int stage) {
   TC *t1 = reinterpret_cast<TC *>(t1v), *t2 = reinterpret_cast<TC *>(t2v);
   const int dim = F.dim; const int64_t nx = F.nn[0], ny = F.nn[1], nz = dim == 3 ? F.nn[2] : 1, nnode = nx * ny * nz;
@@ -686,17 +907,15 @@ template <class TC> static void fdmu_apply_t(hipStream_t s, const FdmU &F, const
     P.nK = F.nn[d]; P.MT = (P.nK + 15) / 16; P.KK = (P.nK + 3) / 4;
     P.SI = d == 0 ? 1 : d == 1 ? nx : nx * ny; P.n_lines = nnode / P.nK; P.comp_stride = nnode; P.ncomp = dim;
     P.x_layout = d == 0 ? 1 : 0; P.ld_line = std::max(P.KK * 4, P.MT * 16) + 2;
-    P.fused = fused ? 1 : 0; P.n0 = (int)nx; P.col0 = 0; P.col_total = P.n_lines; P.reg_form = F.dir[0][d].reg_form ? 1 : 0;
-    P.split = 1; P.split_dir = fwd ? 0 : 1;
-    for (int c = 0; c < dim; ++c) { P.split = P.split && F.dir[c][d].split; P.n_even[c] = F.dir[c][d].n_even; }
+    P.fused = fused ? 1 : 0; P.n0 = (int)nx; P.col0 = 0; P.col_total = P.n_lines;
+    const FdmuDir *dirs[3] = {&F.dir[0][d], &F.dir[dim > 1 ? 1 : 0][d], &F.dir[dim > 2 ? 2 : 0][d]};
+    fill_dir(P, dirs, dim, fwd);
     for (int c = 0; c < dim; ++c) {
       const FdmuDir &D = F.dir[c][d];
       P.T1[c] = (fwd || fused) ? (const void *)D.fwd.p : (const void *)D.bwd.p; P.T2[c] = D.bwd.p;
-      if (fused) {
-        P.lam_d[c] = D.lam.p; P.kd[c] = F.coef[c][d];
-        P.lam0[c] = F.dir[c][0].lam.p; P.k0[c] = F.coef[c][0];
-        P.lam1[c] = dim == 3 ? F.dir[c][1].lam.p : nullptr; P.k1[c] = dim == 3 ? F.coef[c][1] : 0.0;
-      }
+      P.lam_d[c] = D.lam.p; P.kd[c] = F.coef[c][d];
+      P.lam0[c] = F.dir[c][0].lam.p; P.k0[c] = F.coef[c][0];
+      P.lam1[c] = dim == 3 ? F.dir[c][1].lam.p : nullptr; P.k1[c] = dim == 3 ? F.coef[c][1] : 0.0;
     }
     return P;
   };
@@ -706,21 +925,22 @@ template <class TC> static void fdmu_apply_t(hipStream_t s, const FdmU &F, const
     launch_pass<TC, double, TC>(s, P, g, t1);                                    // x forward: g (interleaved) -> t1 (planar)
     if (dim == 3) { P = pass(1, true, false); launch_pass<TC, TC, TC>(s, P, t1, t2); }   // y forward: t1 -> t2
   }
+  TC *cur = dim == 3 ? t2 : t1, *other = dim == 3 ? t1 : t2;                    // where the data are after the leading directions
   if (stage == 2) {                                                               // single rank: last direction forward + scale + backward
     FdmuPass P = pass(last, true, true);
-    if (dim == 3) launch_pass<TC, TC, TC>(s, P, t2, t1); else launch_pass<TC, TC, TC>(s, P, t1, t2);
+    if (P.blk) {                                                                  // long lines: two passes, the scaling rides on the backward pass's loads
+      P.fused = 0; launch_pass<TC, TC, TC>(s, P, cur, other);
+      FdmuPass Q = pass(last, false, false); Q.scale_on_load = 1; launch_pass<TC, TC, TC>(s, Q, other, cur);
+    } else { launch_pass<TC, TC, TC>(s, P, cur, other); std::swap(cur, other); }
   }
   if (stage == 1 || stage == 2) {
-    // 3D: data in t1 (single rank) or t2 (partitioned: scattered back into t2) ; 2D: in t2 (single) / t1 (partitioned)
+    // stage 1 (partitioned): the caller scattered the result of the last direction back into `cur`
     if (dim == 3) {
       FdmuPass P = pass(1, false, false);
-      if (stage == 2) { launch_pass<TC, TC, TC>(s, P, t1, t2); } else { launch_pass<TC, TC, TC>(s, P, t2, t1); }
-      P = pass(0, false, false); P.out_interleaved = 1;
-      if (stage == 2) launch_pass<TC, TC, double>(s, P, t2, z); else launch_pass<TC, TC, double>(s, P, t1, z);
-    } else {
-      FdmuPass P = pass(0, false, false); P.out_interleaved = 1;
-      if (stage == 2) launch_pass<TC, TC, double>(s, P, t2, z); else launch_pass<TC, TC, double>(s, P, t1, z);
+      launch_pass<TC, TC, TC>(s, P, cur, other); std::swap(cur, other);
     }
+    FdmuPass P = pass(0, false, false); P.out_interleaved = 1;
+    launch_pass<TC, TC, double>(s, P, cur, z);
   }
 }
 // copy a (component, planes, columns) window between a planar grid array [c][grid_planes][grid_stride] and a dense, zero-padded block
@@ -748,18 +968,27 @@ void fdmu_apply(hipStream_t s, const FdmU &F, const double *g, double *z, void *
 // the fused last-direction pass on a column-distributed array [component][global line point][C local columns] (partitioned runs)
 template <class TC> static void fdmu_lines_t(hipStream_t s, const FdmU &F, const FdmuDir *last_dir /*[dim]*/, int64_t C, int64_t col0, int64_t ncol_valid, void *in_v, void *out_v) {
   const int dim = F.dim, last = dim - 1;
-  FdmuPass P{};
-  P.nK = last_dir[0].n; P.MT = (P.nK + 15) / 16; P.KK = (P.nK + 3) / 4;
-  P.SI = C; P.n_lines = C; P.comp_stride = (int64_t)P.nK * C; P.ncomp = dim; P.x_layout = 0; P.ld_line = 0;
-  P.fused = 1; P.n0 = F.nn[0]; P.col0 = col0; P.col_total = col0 + ncol_valid; P.reg_form = last_dir[0].reg_form ? 1 : 0;
-  P.split = 1; P.split_dir = 0;
-  for (int c = 0; c < dim; ++c) { P.split = P.split && last_dir[c].split; P.n_even[c] = last_dir[c].n_even; }   // padding columns hold zeros and stay zero
-  for (int c = 0; c < dim; ++c) {
-    P.T1[c] = last_dir[c].fwd.p; P.T2[c] = last_dir[c].bwd.p; P.lam_d[c] = last_dir[c].lam.p; P.kd[c] = F.coef[c][last];
-    P.lam0[c] = F.dir[c][0].lam.p; P.k0[c] = F.coef[c][0];
-    P.lam1[c] = dim == 3 ? F.dir[c][1].lam.p : nullptr; P.k1[c] = dim == 3 ? F.coef[c][1] : 0.0;
-  }
-  launch_pass<TC, TC, TC>(s, P, reinterpret_cast<const TC *>(in_v), reinterpret_cast<TC *>(out_v));
+  auto pass = [&](bool fwd, bool fused) {
+    FdmuPass P{};
+    P.nK = last_dir[0].n; P.MT = (P.nK + 15) / 16; P.KK = (P.nK + 3) / 4;
+    P.SI = C; P.n_lines = C; P.comp_stride = (int64_t)P.nK * C; P.ncomp = dim; P.x_layout = 0; P.ld_line = 0;
+    P.fused = fused ? 1 : 0; P.n0 = F.nn[0]; P.col0 = col0; P.col_total = col0 + ncol_valid;   // padding columns hold zeros and stay zero
+    const FdmuDir *dirs[3] = {&last_dir[0], &last_dir[dim > 1 ? 1 : 0], &last_dir[dim > 2 ? 2 : 0]};
+    fill_dir(P, dirs, dim, fwd);
+    for (int c = 0; c < dim; ++c) {
+      P.T1[c] = (fwd || fused) ? last_dir[c].fwd.p : last_dir[c].bwd.p; P.T2[c] = last_dir[c].bwd.p; P.lam_d[c] = last_dir[c].lam.p; P.kd[c] = F.coef[c][last];
+      P.lam0[c] = F.dir[c][0].lam.p; P.k0[c] = F.coef[c][0];
+      P.lam1[c] = dim == 3 ? F.dir[c][1].lam.p : nullptr; P.k1[c] = dim == 3 ? F.coef[c][1] : 0.0;
+    }
+    return P;
+  };
+  TC *in = reinterpret_cast<TC *>(in_v), *out = reinterpret_cast<TC *>(out_v);
+  FdmuPass P = pass(true, true);
+  if (P.blk) {
+    P.fused = 0; launch_pass<TC, TC, TC>(s, P, in, out);
+    FdmuPass Q = pass(false, false); Q.scale_on_load = 1; launch_pass<TC, TC, TC>(s, Q, out, in);
+    PORO_HIP(hipMemcpyAsync(out, in, sizeof(TC) * (size_t)dim * P.nK * C, hipMemcpyDeviceToDevice, s));
+  } else launch_pass<TC, TC, TC>(s, P, in, out);
 }
 void fdmu_lines(hipStream_t s, const FdmU &F, const FdmuDir *last_dir, int64_t C, int64_t col0, int64_t ncol_valid, void *in, void *out) {
   if (F.single) fdmu_lines_t<float>(s, F, last_dir, C, col0, ncol_valid, in, out); else fdmu_lines_t<double>(s, F, last_dir, C, col0, ncol_valid, in, out);

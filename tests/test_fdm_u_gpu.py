@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 # (dim, cells, degree, Dirichlet list): uneven boxes catch direction mix-ups; the mixed lists put one component on faces of several directions
 MIXED_3D = [(0, 0, 0.0), (1, 0, -1e-5), (2, 1, 0.0), (3, 1, -1e-5), (4, 2, 0.0), (2, 0, 2e-6), (5, 1, 0.0)]
 MIXED_2D = [(0, 0, 0.0), (2, 1, 0.0), (3, 0, 1e-6)]
-CASES = [(3, (4, 3, 5), 2, BC_3D), (3, (5, 4, 3), 1, BC_3D), (3, (3, 4, 2), 2, MIXED_3D), (2, (6, 5), 2, BC_2D), (2, (7, 4), 1, MIXED_2D), (3, (9, 2, 3), 2, BC_3D)]
+# the last three have lines of more than 160 points in one or two directions: the blocked even / odd kernel (k_fdmu_blk), mixed with the register forms
+CASES = [(3, (4, 3, 5), 2, BC_3D), (3, (5, 4, 3), 1, BC_3D), (3, (3, 4, 2), 2, MIXED_3D), (2, (6, 5), 2, BC_2D), (2, (7, 4), 1, MIXED_2D), (3, (9, 2, 3), 2, BC_3D),
+         (2, (100, 90), 2, BC_2D), (3, (170, 3, 2), 1, BC_3D), (2, (5, 230), 1, BC_2D)]
 
 
 def block_inverse(A, mask, dim, g):
@@ -54,7 +56,7 @@ def test_block_fdm_equals_the_block_inverse(dim, n, deg, bc):
         G.close(); O.close(); P.close()
 
 
-@pytest.mark.parametrize("dim,n,deg", [(3, 6, 2), (2, 12, 2), (3, 7, 1)], ids=str)
+@pytest.mark.parametrize("dim,n,deg", [(3, 6, 2), (2, 12, 2), (3, 7, 1), (2, (120, 30), 2)], ids=str)
 def test_block_fdm_cg_solves_like_the_oracle(dim, n, deg):
     """nonuniform pressure -> displacement solve: same u as the oracle's SSOR-CG (both to the recursive residual 1e-12 |b|), few iterations"""
     P = box_problem(dim, n, deg)

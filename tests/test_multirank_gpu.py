@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("world,dim,n,deg,backend", [(2, 3, (3, 3, 6), 2, "hip_mf"), (2, 3, (4, 4, 6), 1, "hip_csr"), (2, 2, (8, 12), 2, "hip_mf"),
                                                       (3, 3, (4, 5, 7), 1, "hip_mf"), (3, 2, (9, 10), 2, "hip_mf"), (4, 3, (3, 3, 9), 2, "hip_mf"),
                                                       (2, 3, (3, 4, 6), 2, "hip_mf_fdm"), (3, 2, (9, 10), 2, "hip_mf_fdm"), (3, 3, (4, 5, 7), 1, "hip_mf_fdm"), (4, 3, (5, 3, 9), 2, "hip_mf_fdm"),
-                                                      (2, 3, (3, 4, 6), 2, "hip_mf_cheb"), (3, 2, (9, 10), 2, "hip_mf_cheb")])
+                                                      (2, 3, (3, 4, 6), 2, "hip_mf_cheb"), (3, 2, (9, 10), 2, "hip_mf_cheb"), (2, 2, (6, 170), 1, "hip_mf_fdm")])
 def test_ranks_on_one_gpu(tmp_path, world, dim, n, deg, backend):
     """2 and 3 ranks (uneven slabs, column groups that do not divide evenly): halo exchange, all-reduced dots, and the distributed
     fast-diagonalisation solves of the pressure / projection systems (all-to-all of column groups)."""
