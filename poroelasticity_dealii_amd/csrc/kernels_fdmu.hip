@@ -54,7 +54,7 @@ struct FdmuPass {
   int split_dir;        // split, not fused: 0 forward (nodes -> modes), 1 backward
   int n_even[3];        // split: even modes per component (mode order along the line: even modes first, then the odd ones)
   int blk;              // split form for lines of more than 160 points (k_fdmu_blk): the output rows are produced in blocks of 80 per parity, the transform matrix is
-  int blk_kk, blk_nch, blk_mb;   //   packed [row block][chunk]...; k-steps, chunks per row block and row blocks of THIS pass (forward / backward differ)
+  int blk_kk[3], blk_nch[3], blk_mb[3];   //   packed [row block][chunk]...; per component: k-steps, chunks per row block and row blocks of THIS pass (forward / backward differ)
   int scale_on_load;    // blk backward pass of the last direction: the coefficients are divided by the eigenvalue sums as they are loaded
   const void *T1[3], *T2[3];             // per component: transform matrices in MFMA fragment order [MT][KK][64]
   const double *lam_d[3], *lam0[3], *lam1[3];
@@ -470,7 +470,7 @@ k_fdmu_blk(FdmuPass P, const double *__restrict__ in, double *__restrict__ out) 
   const double *in_lane = in + (P.in_interleaved ? lb * P.ncomp + c : (int64_t)c * P.comp_stride + lb);
   double *out_lane = out + (P.out_interleaved ? lb * P.ncomp + c : (int64_t)c * P.comp_stride + lb);
   const int nn = P.nK, h = (nn + 1) / 2, ne = P.n_even[c], k_last = nn - 1;
-  const int NCHK = P.blk_nch, KK = P.blk_kk;
+  const int NCHK = P.blk_nch[c], KK = P.blk_kk[c];
   double base = 0; const double *lam_lane = nullptr; double kdc = 0;
   if (MODE == 1 && P.scale_on_load) {
     const int64_t col = min(P.col0 + nc, P.col_total - 1);
@@ -499,7 +499,8 @@ k_fdmu_blk(FdmuPass P, const double *__restrict__ in, double *__restrict__ out) 
       }
     }
   };
-  for (int mb = 0; mb < P.blk_mb; ++mb) {
+  // one row block per workgroup (grid z): a 2D mesh has few lines (673 per component at config 2), the row blocks supply the missing parallelism
+  for (int mb = blockIdx.z; mb < P.blk_mb[c]; mb += gridDim.z) {
     v4d acc[2 * PP];
 #pragma unroll
     for (int t = 0; t < 2 * PP; ++t) acc[t] = v4d{0, 0, 0, 0};
@@ -564,8 +565,10 @@ void launch_split(hipStream_t s, const FdmuPass &P, const double *in, double *ou
   const dim3 grid((unsigned)((P.n_lines + 63) / 64), (unsigned)P.ncomp);
   if (P.blk) {
     if (P.fused) throw Error("launch_split: the blocked form runs the last direction as two passes");
-    if (P.split_dir == 0) hipLaunchKernelGGL((k_fdmu_blk<0>), grid, dim3(kThreads), 0, s, P, in, out);
-    else hipLaunchKernelGGL((k_fdmu_blk<1>), grid, dim3(kThreads), 0, s, P, in, out);
+    int mbz = 1; for (int c = 0; c < P.ncomp; ++c) mbz = std::max(mbz, P.blk_mb[c]);
+    const dim3 gridz(grid.x, grid.y, (unsigned)mbz);
+    if (P.split_dir == 0) hipLaunchKernelGGL((k_fdmu_blk<0>), gridz, dim3(kThreads), 0, s, P, in, out);
+    else hipLaunchKernelGGL((k_fdmu_blk<1>), gridz, dim3(kThreads), 0, s, P, in, out);
     return;
   }
   const int mode = P.fused ? 2 : P.split_dir;
@@ -779,6 +782,25 @@ void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::ve
     for (int i = 0; i < nf; ++i) S[(size_t)(i + f0) * nn + j] = sv[i];
     lam[j] = std::max(wv[j], 0.0);
   }
+  // the same condition at both ends: M and K are persymmetric, every eigenvector is symmetric or antisymmetric about the centre up to the rounding of
+  // the eigen-solver (1e-9 for the clustered top of a 671-point spectrum).  Make that exact - the even / odd transform kernels rely on it - and restore
+  // the M-normalisation.
+  if (fix_lo == fix_hi)
+    for (int j = 0; j < nf; ++j) {
+      double ds = 0, da = 0;
+      for (int k = 0; k < nn; ++k) { const double a = S[(size_t)k * nn + j], b = S[(size_t)(nn - 1 - k) * nn + j]; ds += (a - b) * (a - b); da += (a + b) * (a + b); }
+      const double sgn = ds <= da ? 1.0 : -1.0;
+      if (std::min(ds, da) > 1e-8 * std::max(ds, da)) continue;         // (not the expected structure: left alone, the full-length kernels take over)
+      for (int k = 0; k < nn / 2; ++k) {
+        const double a = S[(size_t)k * nn + j], b = S[(size_t)(nn - 1 - k) * nn + j], v = 0.5 * (a + sgn * b);
+        S[(size_t)k * nn + j] = v; S[(size_t)(nn - 1 - k) * nn + j] = sgn * v;
+      }
+      if ((nn & 1) && sgn < 0) S[(size_t)(nn / 2) * nn + j] = 0.0;
+      double nrm = 0;
+      for (int i = 0; i < nn; ++i) { double t = 0; for (int p = std::max(0, i - 2 * k); p <= std::min(nn - 1, i + 2 * k); ++p) t += M[(size_t)i * nn + p] * S[(size_t)p * nn + j]; nrm += S[(size_t)i * nn + j] * t; }
+      const double sc = 1.0 / std::sqrt(nrm);
+      for (int i = 0; i < nn; ++i) S[(size_t)i * nn + j] *= sc;
+    }
 }
 
 double sym_lambda_max(int n, const std::vector<double> &A) {
@@ -896,8 +918,7 @@ static void fill_dir(FdmuPass &P, const FdmuDir *const dirs[3], int dim, bool fw
   P.split = 1; P.split_dir = fwd ? 0 : 1; P.blk = 1;
   for (int c = 0; c < dim; ++c) { P.split = P.split && dirs[c]->split; P.blk = P.blk && dirs[c]->blk; P.n_even[c] = dirs[c]->n_even; }
   if (!P.split) P.blk = 0;
-  if (P.blk) { const int w = fwd ? 0 : 1; P.blk_kk = dirs[0]->blk_kk[w]; P.blk_nch = dirs[0]->blk_nch[w]; P.blk_mb = dirs[0]->blk_mb[w];
-               for (int c = 1; c < dim; ++c) { P.blk_kk = std::max(P.blk_kk, dirs[c]->blk_kk[w]); } }
+  if (P.blk) { const int w = fwd ? 0 : 1; for (int c = 0; c < dim; ++c) { P.blk_kk[c] = dirs[c]->blk_kk[w]; P.blk_nch[c] = dirs[c]->blk_nch[w]; P.blk_mb[c] = dirs[c]->blk_mb[w]; } }
 }
 template <class TC> static void fdmu_apply_t(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1v, void *t2v, int stage) {
   TC *t1 = reinterpret_cast<TC *>(t1v), *t2 = reinterpret_cast<TC *>(t2v);
