@@ -139,6 +139,12 @@ typedef struct poro_desc {
   poro_partition  part;
   poro_constraints cons_u;   /* displacement space (n = 0: none) */
   poro_constraints cons_p;   /* pressure space; also used by the strain projection (StrainProjector.h:191-194) */
+  /* EXTENSION (not in the reference, whose pressure space has "no dirichlet pressure BC's", PoroElasticPressureSolver.h:69-70): prescribed pressures,
+   * e.g. a drained boundary p = 0.  Needed to validate the corrected-physics switches on Terzaghi's consolidation problem.  The rows are
+   * taken out of the pressure Newton system (residual 0, update 0); poro_pres_apply_boundary_values writes the values into PORO_VEC_P. */
+  int64_t n_dirichlet_p;
+  const int32_t *dirichlet_dof_p;
+  const double  *dirichlet_value_p;
 } poro_desc;
 
 /* Krylov controls.  Reference values: displacement abs 1e-12, 1000 its
@@ -237,6 +243,8 @@ int  poro_supports_preconditioner(poro_ctx *ctx, int32_t which_system, int32_t p
 
 /* PoroElasticPressureSolver<dim>::assemble_residual (:113-155) from PORO_VEC_{P,P_OLD,EPSV,EPSV0}; l2 = residual.l2_norm() (PoroelasticityFSS.h:364) */
 int  poro_pres_assemble_residual(poro_ctx *ctx, double time_step, double *l2);
+/* extension: PORO_VEC_P[dof] = value on the prescribed-pressure dofs of the descriptor; a no-op without any; call after setting the initial pressure */
+int  poro_pres_apply_boundary_values(poro_ctx *ctx);
 /* PoroElasticPressureSolver<dim>::assemble_jacobian (:158-169) */
 int  poro_pres_assemble_jacobian(poro_ctx *ctx, double time_step);
 /* PoroElasticPressureSolver<dim>::solve (:172-185): J dp = R into PORO_VEC_DP (warm start) */

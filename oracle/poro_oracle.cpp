@@ -268,6 +268,7 @@ struct Oracle {
   int tensor_to_entry[9];
   int64_t work[6] = {0, 0, 0, 0, 0, 0};   // apply_u, apply_p, asm_rhs_u, residual_p, jacobian_p, proj_rhs (same units as the host driver's counters)
   Cons cons_u, cons_p;      // hanging-node constraints of the two spaces (empty on uniform meshes)
+  std::vector<char> is_pdir; Vec pdir_val; bool any_pdir = false;   // EXTENSION (not in the reference): prescribed pressures, e.g. a drained boundary (include/poroel_hip.h)
   int stop_rule_u = 0;      // stopping rule of the displacement solve (see cg)
   int n_noconvergence = 0;  // SolverControl::NoConvergence would have been thrown this many times
 
@@ -283,6 +284,8 @@ struct Oracle {
     nlab.assign(d.neumann_label, d.neumann_label + d.n_neumann); ncomp.assign(d.neumann_component, d.neumann_component + d.n_neumann); nval.assign(d.neumann_value, d.neumann_value + d.n_neumann);
     mat = d.mat; comm.part = d.part;
     cons_u.init(d.cons_u); cons_p.init(d.cons_p);
+    is_pdir.assign(d.n_dofs_p, 0); pdir_val.assign(d.n_dofs_p, 0.0); any_pdir = d.n_dirichlet_p > 0;
+    for (int64_t i = 0; i < d.n_dirichlet_p; ++i) { is_pdir[d.dirichlet_dof_p[i]] = 1; pdir_val[d.dirichlet_dof_p[i]] = d.dirichlet_value_p[i]; }
     // TensorIndexer.h:18-35
     if (dim == 2) { const int t[4] = {0, 1, 1, 2}; std::copy(t, t + 4, tensor_to_entry); }
     else { const int t[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5}; std::copy(t, t + 9, tensor_to_entry); }
@@ -446,10 +449,11 @@ struct Oracle {
   // Multi-rank: the local matrix holds this slab's partial rows; shared-plane rows are completed by exchange_add.
   // stop_rule 0: ||g|| <= max(abs_tol, rel_tol ||b||) (the reference's SolverControl objects); 1: rel_tol against the residual of the warm
   // start (deal.II ReductionControl) - the stated rule of the transient benchmark, mirrored from include/poroel_hip.h PORO_STOP_REDUCTION
-  SolveInfo cg(const Csr &M, Vec &x, const Vec &b, double abs_tol, double rel_tol, int max_iter, int prec, double omega, int64_t plane, int stop_rule = 0, const Cons *cons = nullptr) {
+  SolveInfo cg(const Csr &M, Vec &x, const Vec &b, double abs_tol, double rel_tol, int max_iter, int prec, double omega, int64_t plane, int stop_rule = 0, const Cons *cons = nullptr,
+               const std::vector<char> *frozen = nullptr) {
     const int64_t n = M.n; Vec g(n), dvec(n), h(n), diagv, tmp;
     if (cons && !cons->any()) cons = nullptr;
-    if (cons && prec == 2) prec = 1;   // the condensed matrix exists at operator level only: Jacobi instead of the SSOR sweeps
+    if ((cons || frozen) && prec == 2) prec = 1;   // the condensed matrix exists at operator level only: Jacobi instead of the SSOR sweeps
     SolveInfo info;
     int64_t &napply = work[&M == &A ? 0 : 1];
     if (prec == 1 || comm.multi()) { diagv.resize(n); for (int64_t r = 0; r < n; ++r) diagv[r] = M.val[M.diag[r]]; comm.exchange_add(diagv, plane); }
@@ -457,6 +461,7 @@ struct Oracle {
     auto apply = [&](Vec &y, const Vec &v) {
       if (cons) { tmp = v; cons->expand(tmp, false); M.vmult(y, tmp); cons->reduce(y); }
       else M.vmult(y, v);
+      if (frozen) for (int64_t i = 0; i < n; ++i) if ((*frozen)[i]) y[i] = 0.0;   // rows taken out of the system (their unknowns stay at the warm start's value)
       comm.exchange_add(y, plane); ++napply;
     };
     auto precond = [&](Vec &y, const Vec &v) {
@@ -525,6 +530,7 @@ struct Oracle {
     well_source(source);                                                                            // :142-147
     for (int64_t i = 0; i < n; ++i) { residual[i] += source[i]; residual[i] *= -1; }                 // :148,152
     cons_p.reduce(residual);                                                                        // constraints.condense(residual) :153
+    if (any_pdir) for (int64_t i = 0; i < n; ++i) if (is_pdir[i]) residual[i] = 0.0;                  // extension: prescribed-pressure rows
     work[3]++;
     return std::sqrt(comm.dot(residual, residual, d.part.plane_p));                                 // PoroelasticityFSS.h:364
   }
@@ -535,7 +541,7 @@ struct Oracle {
   }
   // PoroElasticPressureSolver::solve :172-185
   SolveInfo pres_solve(double abs_tol, double rel_tol, int max_iter, int prec, double omega) {
-    SolveInfo s = cg(Jp, dp, residual, abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_p, 0, &cons_p);   // condensed Jacobian :168
+    SolveInfo s = cg(Jp, dp, residual, abs_tol, rel_tol, max_iter, prec, omega, d.part.plane_p, 0, &cons_p, any_pdir ? &is_pdir : nullptr);   // condensed Jacobian :168
     cons_p.expand(dp, true);                                                                        // constraints.distribute :180
     return s;
   }
@@ -760,6 +766,7 @@ int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_
   for (Vec &v : o->strains) std::fill(v.begin(), v.end(), 0.0);
   for (Vec &v : o->proj_rhs) std::fill(v.begin(), v.end(), 0.0);
   std::fill(o->p.begin(), o->p.end(), p_init);                     // :311
+  if (o->any_pdir) for (int64_t i = 0; i < o->d.n_dofs_p; ++i) if (o->is_pdir[i]) o->p[i] = o->pdir_val[i];   // extension: prescribed pressures
   double t0 = now(); std::fill(o->A.val.begin(), o->A.val.end(), 0.0); o->rebuild_system_matrix = true; o->assemble_system(); tph[0] += now() - t0;   // :312
   t0 = now(); SolveInfo su = o->disp_solve(abs_u, rel_u, max_it, prec, om_u); tph[1] += now() - t0;   // :313
   o->assemble_projection_matrix();                                 // :314

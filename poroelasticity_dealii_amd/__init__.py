@@ -54,7 +54,8 @@ class Desc(C.Structure):
                 ("n_bfaces", C.c_int64), ("bface_cell", _ip), ("bface_local", _ip), ("bface_id", _ip),
                 ("n_dirichlet", C.c_int64), ("dirichlet_dof", _ip), ("dirichlet_value", _dp),
                 ("n_neumann", C.c_int32), ("neumann_label", _ip), ("neumann_component", _ip), ("neumann_value", _dp),
-                ("mat", Material), ("box", Structured), ("part", Partition), ("cons_u", Constraints), ("cons_p", Constraints)]
+                ("mat", Material), ("box", Structured), ("part", Partition), ("cons_u", Constraints), ("cons_p", Constraints),
+                ("n_dirichlet_p", C.c_int64), ("dirichlet_dof_p", _ip), ("dirichlet_value_p", _dp)]
 
 
 class SolverOpts(C.Structure):
@@ -87,7 +88,7 @@ SENDRECV_FN = C.CFUNCTYPE(None, _dp, _dp, C.c_int64, C.c_int32, C.c_void_p)
 HIP_SYMBOLS = [
     "poro_last_error", "poro_abi_version", "poro_ctx_create", "poro_ctx_destroy", "poro_comm_unique_id", "poro_ctx_comm_init_rccl",
     "poro_ctx_comm_init_callbacks", "poro_vec_set", "poro_vec_get", "poro_vec_fill", "poro_vec_copy", "poro_vec_axpy", "poro_vec_norm",
-    "poro_state_save", "poro_state_restore", "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_assemble_jacobian", "poro_pres_solve",
+    "poro_state_save", "poro_state_restore", "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_apply_boundary_values", "poro_pres_assemble_jacobian", "poro_pres_solve",
     "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain", "poro_get_effective_stresses",
     "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_apply_preconditioner_u", "poro_bench_operator", "poro_timers_reset", "poro_timers_enable", "poro_timers_get"]
 
@@ -126,6 +127,7 @@ def load_hip():
         L.poro_supports_preconditioner.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.poro_pres_assemble_residual.argtypes = [C.c_void_p, C.c_double, _dp]
         L.poro_pres_assemble_jacobian.argtypes = [C.c_void_p, C.c_double]
+        L.poro_pres_apply_boundary_values.argtypes = [C.c_void_p]
         L.poro_pres_solve.argtypes = [C.c_void_p, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]
         L.poro_pres_update_volumetric_strain.argtypes = [C.c_void_p]
         L.poro_proj_assemble_matrix.argtypes = [C.c_void_p]
@@ -159,6 +161,7 @@ def load_host():
         L.poro_host_build_refined_box.argtypes = [C.c_int, _ip, _dp, C.c_int, _ip, _ip] + bc
         L.poro_host_build_gmsh.restype = C.c_void_p
         L.poro_host_build_gmsh.argtypes = [C.c_char_p, C.c_int] + bc
+        L.poro_host_set_pressure_bc.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
         L.poro_host_desc.restype = C.POINTER(Desc)
         L.poro_host_desc.argtypes = [C.c_void_p]
         L.poro_host_free.argtypes = [C.c_void_p]
@@ -240,6 +243,14 @@ class Problem:
     def gmsh(cls, path, degree_u, material, dirichlet, neumann=()):
         keep, args = cls._bc(dirichlet, neumann)
         return cls(load_host().poro_host_build_gmsh(path.encode(), degree_u, *args, C.byref(material)))
+
+    def set_pressure_bc(self, conditions):
+        """extension (the reference has no pressure boundary conditions): prescribed pressure [(boundary label, value)], e.g. a drained face p = 0"""
+        lab, pl = _arr_i([c[0] for c in conditions]); val, pv = _arr_d([c[1] for c in conditions])
+        if load_host().poro_host_set_pressure_bc(self.handle, len(conditions), pl, pv) != 0:
+            raise RuntimeError(load_host().poro_host_last_error().decode())
+        self.desc = self.desc_ptr.contents
+        return self
 
     def close(self):
         if self.handle:
@@ -333,6 +344,9 @@ class Context:
 
     def pres_assemble_jacobian(self, dt):
         self._chk(self.L.poro_pres_assemble_jacobian(self.ptr, dt))
+
+    def pres_apply_boundary_values(self):
+        self._chk(self.L.poro_pres_apply_boundary_values(self.ptr))
 
     def pres_solve(self, abs_tol=0.0, rel_tol=1e-8, max_iter=1000, prec=PREC_JACOBI, omega=1.0):
         info = SolveInfo()

@@ -132,6 +132,7 @@ struct poro_ctx {
   poro::DevBuf<uint8_t> dir_mask, node_mask; poro::DevBuf<double> dir_val; poro::DevBuf<int32_t> dir_dofs;
   std::vector<int32_t> h_dir_dof; std::vector<double> h_dir_val;
   poro::ConsDev cons_u, cons_p;
+  poro::DevBuf<uint8_t> pdir_mask; poro::DevBuf<double> pdir_val; int64_t n_pdir = 0;   // extension: prescribed pressures
   poro::DevBuf<int32_t> bface_cell, bface_local, bface_id, neu_label, neu_comp; poro::DevBuf<double> neu_val;
   int64_t n_bfaces = 0; int n_neumann = 0;
   // matrices

@@ -762,7 +762,14 @@ void setup(poro_ctx *c, const poro_desc *d) {
       if (c->comm.part.n_ranks > 1) throw Error("constraint lists are implemented for one rank");
     }
     upload_constraints(c->cons_u, d->cons_u, c->n_u, &m, "cons_u");
-    upload_constraints(c->cons_p, d->cons_p, c->n_p, nullptr, "cons_p");
+    { // extension: prescribed pressures (drained boundaries); the rows leave the pressure Newton system exactly like hanging rows do
+      std::vector<uint8_t> pm(c->n_p, 0); std::vector<double> pv(c->n_p, 0.0);
+      if (d->n_dirichlet_p < 0 || (d->n_dirichlet_p && (!d->dirichlet_dof_p || !d->dirichlet_value_p))) throw Error("bad prescribed-pressure list");
+      for (int64_t i = 0; i < d->n_dirichlet_p; ++i) { const int32_t dof = d->dirichlet_dof_p[i]; if (dof < 0 || dof >= c->n_p) throw Error("dirichlet_dof_p out of range"); pm[dof] = 1; pv[dof] = d->dirichlet_value_p[i]; }
+      c->n_pdir = d->n_dirichlet_p;
+      if (c->n_pdir) { if (c->comm.part.n_ranks > 1) throw Error("prescribed pressures are implemented for one rank"); c->pdir_mask.upload(pm); c->pdir_val.upload(pv); }
+      upload_constraints(c->cons_p, d->cons_p, c->n_p, &pm, "cons_p");
+      if (c->cons_p.n && c->n_pdir) throw Error("prescribed pressures together with hanging pressure nodes are not supported"); }
     { std::vector<uint8_t> nm((size_t)(c->n_u / c->dim), 0); for (int64_t i = 0; i < d->n_dirichlet; ++i) nm[d->dirichlet_dof[i] / c->dim] |= (uint8_t)(1u << (d->dirichlet_dof[i] % c->dim)); c->node_mask.upload(nm); c->h_node_mask = std::move(nm); }
     if (d->n_dirichlet) c->dir_dofs.upload(d->dirichlet_dof, d->n_dirichlet);
     if (d->box.enabled) {   // are all constrained dofs on the box boundary?  (lets the matrix-free kernels skip mask loads in the interior)
@@ -1130,7 +1137,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
 int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec) {
   if (!c) return 0;
   if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
-  if (which_system == 0 ? c->cons_u.n : c->cons_p.n) return 0;   // condensed operators exist at operator level only: Jacobi
+  if (which_system == 0 ? c->cons_u.n : (c->cons_p.n || c->n_pdir)) return 0;   // condensed operators exist at operator level only: Jacobi
   if (prec == PORO_PREC_SSOR || prec == PORO_PREC_ILU0) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
   if (prec == PORO_PREC_CHEBYSHEV) return which_system == 0;
   if (prec == PORO_PREC_FDM && which_system == 1) return fdm_p_supported(c);
@@ -1275,11 +1282,20 @@ int poro_pres_assemble_residual(poro_ctx *c, double dt, double *l2) {
     }
     exchange_add(c, R, c->n_p, c->comm.part.plane_p);
     la_cons_reduce(s, c->cons_p, R);                                              // constraints.condense(residual) (:153)
+    if (c->n_pdir) la_mask_zero(s, R, c->pdir_mask.p, c->n_p);                    // prescribed-pressure rows are not part of the Newton system
     la_dot_partials(s, R, R, owned(c, c->n_p, c->comm.part.plane_p), c->partials.p);
     la_reduce_finish(s, c->partials.p, 1, c->red.p, 0);
     allreduce_sum(c, c->red.p, 1);
     double h; PORO_HIP(hipMemcpyAsync(&h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
     if (l2) *l2 = std::sqrt(h);
+    return 0;
+  });
+}
+
+int poro_pres_apply_boundary_values(poro_ctx *c) {
+  return guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    if (c->n_pdir) la_set_constrained(c->stream, vec(c, PORO_VEC_P), c->pdir_mask.p, c->pdir_val.p, c->n_p);
     return 0;
   });
 }
@@ -1295,7 +1311,7 @@ int poro_pres_assemble_jacobian(poro_ctx *c, double dt) {
     exchange_add(c, c->diag_J.p, c->n_p, c->comm.part.plane_p);
     if (!c->dinv_J.p) c->dinv_J.alloc(c->n_p);
     la_reciprocal(c->stream, c->dinv_J.p, c->diag_J.p, c->n_p);
-    if (c->cons_p.n) la_mask_zero(c->stream, c->dinv_J.p, c->cons_p.inert.p, c->n_p);
+    if (c->cons_p.n || c->n_pdir) la_mask_zero(c->stream, c->dinv_J.p, c->cons_p.inert.p, c->n_p);
     c->ilu_J_valid = false;
     c->jac_dt = dt;
     return 0;
@@ -1306,7 +1322,7 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (c->jac_dt < 0) throw Error("pres_solve before pres_assemble_jacobian");
-    if (c->cons_p.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE) throw Error("meshes with hanging-node constraints: PORO_PREC_JACOBI / NONE only");
+    if ((c->cons_p.n || c->n_pdir) && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE) throw Error("meshes with hanging-node constraints or prescribed pressures: PORO_PREC_JACOBI / NONE only");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       return pcg_ilu0(c, c->Ap, c->Jp.p, c->ilu_J, c->ilu_J_valid, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     }
@@ -1328,7 +1344,7 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       DiagVec dz; dz.full = c->dinv_J.p; dz.z = c->wz_p.p;
       return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
     }
-    DiagVec dv; dv.full = c->dinv_J.p; dv.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
+    DiagVec dv; dv.full = c->dinv_J.p; dv.inert = (c->cons_p.n || c->n_pdir) ? c->cons_p.inert.p : nullptr;
     const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_DP), true);              // constraints.distribute(solution_update) (:180)
     return rc;

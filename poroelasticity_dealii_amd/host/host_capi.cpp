@@ -64,6 +64,15 @@ void *poro_host_build_gmsh(const char *path, int k_u,
   } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 
+// extension: prescribed pressures on boundary labels (before the context is created)
+int poro_host_set_pressure_bc(void *h, int n, const int32_t *labels, const double *values) {
+  try {
+    auto *P = static_cast<ProblemData *>(h);
+    P->bc.pressure_labels.assign(labels, labels + n); P->bc.pressure_values.assign(values, values + n);
+    P->set_pressure_bc();
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 const poro_desc *poro_host_desc(void *h) { return &static_cast<ProblemData *>(h)->d; }
 void poro_host_free(void *h) { delete static_cast<ProblemData *>(h); }
 

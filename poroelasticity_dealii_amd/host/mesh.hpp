@@ -184,6 +184,7 @@ inline DoFs distribute_dofs(const Mesh &m, int k_u) {
 struct BoundaryConditions {  // BoundaryConditions.h:6-62
   std::vector<int32_t> dirichlet_labels, dirichlet_components, neumann_labels, neumann_components;
   std::vector<double>  dirichlet_values, neumann_values;
+  std::vector<int32_t> pressure_labels; std::vector<double> pressure_values;   // extension: prescribed pressure on whole boundary faces (drained boundary)
 };
 
 // VectorTools::interpolate_boundary_values(label, ConstantFunction(value), constraints, mask[component])
@@ -312,10 +313,25 @@ inline RefinedBox make_refined_box(int dim, const int n[3], const double origin[
   return R;
 }
 
+// extension: prescribed pressure on the faces carrying the given labels (first condition wins, like the displacement conditions)
+inline void make_dirichlet_p(const Mesh &m, const DoFs &D, const BoundaryConditions &bc, std::vector<int32_t> &dofs, std::vector<double> &values) {
+  const int dim = m.dim, nv = 1 << dim;
+  std::map<int32_t, double> cons;
+  for (size_t cond = 0; cond < bc.pressure_labels.size(); ++cond)
+    for (size_t bf = 0; bf < m.bface_cell.size(); ++bf) {
+      if (m.bface_id[bf] != bc.pressure_labels[cond]) continue;
+      const int64_t c = m.bface_cell[bf]; const int f = m.bface_local[bf], nd = f / 2, side = f % 2;
+      for (int v = 0; v < nv; ++v) if (((v >> nd) & 1) == side) cons.emplace(D.cell_p[c * nv + v], bc.pressure_values[cond]);
+    }
+  dofs.clear(); values.clear();
+  for (auto &kv : cons) { dofs.push_back(kv.first); values.push_back(kv.second); }
+}
+
 // Everything poro_desc points at, owned in one place.
 struct ProblemData {
   Mesh mesh; DoFs dofs; FETables fe; BoundaryConditions bc;
   std::vector<int32_t> dirichlet_dof; std::vector<double> dirichlet_value;
+  std::vector<int32_t> dirichlet_dof_p; std::vector<double> dirichlet_value_p;
   poro_material mat{}; poro_partition part{};
   ConstraintList cons_u, cons_p;      // hanging-node constraints (locally refined meshes)
   poro_desc d{};
@@ -360,6 +376,11 @@ struct ProblemData {
     if (part.n_ranks == 0) { part.n_ranks = 1; part.rank = 0; }
     d.part = part;
     d.cons_u = cons_u.c_view(); d.cons_p = cons_p.c_view();
+    set_pressure_bc();
+  }
+  void set_pressure_bc() {
+    make_dirichlet_p(mesh, dofs, bc, dirichlet_dof_p, dirichlet_value_p);
+    d.n_dirichlet_p = (int64_t)dirichlet_dof_p.size(); d.dirichlet_dof_p = dirichlet_dof_p.data(); d.dirichlet_value_p = dirichlet_value_p.data();
   }
 };
 

@@ -255,6 +255,7 @@ template <int dim> class PoroElasticProblem {
         : poro_supports_preconditioner(context(), 1, PORO_PREC_FDM) ? PORO_PREC_FDM : PORO_PREC_JACOBI;
     setup_dofs();                                          // :308
     pressure_solver.solution = rc.p_init;                  // :311
+    check(poro_pres_apply_boundary_values(ctx), "pres_apply_boundary_values");   // (extension: prescribed pressures; no-op for the reference's problems)
     assemble_displacement();                               // :312
     solve_displacement();                                  // :313
     strain_projector.assemble_projection_matrix();         // :314
