@@ -87,7 +87,7 @@ typedef struct poro_structured {
   double  h[3];
 } poro_structured;
 
-/* Slab partition of a structured box over ranks.  The local mesh is
+/* Partition over ranks.  Slab form for a structured box:  The local mesh is
  * the rank's slab as a standalone box; node planes at the low / high end in the
  * slowest direction are shared with the neighbour rank when has_lower/has_upper. */
 typedef struct poro_partition {
@@ -95,6 +95,19 @@ typedef struct poro_partition {
   int32_t has_lower, has_upper;
   int64_t plane_u;   /* u dofs on one interface plane  */
   int64_t plane_p;   /* p dofs on one interface plane  */
+  /* General partition (any mesh; SURVEY 8e: contiguous cell ranges + an indexed interface list), used when n_neighbours > 0 (then has_lower /
+   * has_upper / plane_* are ignored).  The local mesh is the rank's cells as a standalone mesh; a dof touched by cells of several ranks is
+   * local to each of them.  Local dofs [0, n_owned) are the ones this rank owns (every shared dof has exactly one owner; dots run over owned
+   * dofs), the others follow.  shared_dof_*[shared_ptr_*[k] .. shared_ptr_*[k+1]) are the local dofs shared with rank neighbour_rank[k], listed
+   * in the SAME order on both sides (e.g. ascending global index); a dof shared by three ranks appears in two lists on each of them.  Partial
+   * sums are exchanged pairwise and added in ascending rank order, so every rank holding a dof computes bitwise the same value. */
+  int32_t n_neighbours;
+  const int32_t *neighbour_rank;   /* [n_neighbours], ascending, without `rank` */
+  const int64_t *shared_ptr_u;     /* [n_neighbours + 1] */
+  const int32_t *shared_dof_u;
+  const int64_t *shared_ptr_p;     /* [n_neighbours + 1] */
+  const int32_t *shared_dof_p;
+  int64_t n_owned_u, n_owned_p;
 } poro_partition;
 
 /* Closed affine constraints beyond the Dirichlet list: the hanging nodes of a locally refined mesh (DoFTools::make_hanging_node_constraints,

@@ -211,17 +211,43 @@ struct Csr {
 struct Comm {
   poro_allreduce_fn ar = nullptr; poro_sendrecv_fn sr = nullptr; void *user = nullptr;
   poro_partition part{};
+  int64_t n_u = 0;       // length of displacement vectors: tells the two spaces of a general partition apart
   bool multi() const { return part.n_ranks > 1; }
-  // add the neighbour's partial sums on the shared planes (rows assembled from both slabs)
+  bool general() const { return part.n_neighbours > 0; }
+  // add the neighbours' partial sums on the shared dofs (rows assembled from cells of several ranks)
   void exchange_add(Vec &v, int64_t plane) const {
     if (!multi()) return;
-    Vec rbuf(plane);
     const int64_t n = (int64_t)v.size();
+    if (general()) {
+      // pairwise exchange with every neighbour, then the sum in ascending rank order (own contribution at its place): bitwise the same on every
+      // rank holding the dof (poroel_hip.h, poro_partition)
+      const int64_t *ptr = n == n_u ? part.shared_ptr_u : part.shared_ptr_p; const int32_t *dof = n == n_u ? part.shared_dof_u : part.shared_dof_p;
+      const int nn = part.n_neighbours; Vec sbuf(ptr[nn]), rbuf(ptr[nn]);
+      for (int64_t j = 0; j < ptr[nn]; ++j) sbuf[j] = v[dof[j]];
+      for (int k = 0; k < nn; ++k) if (ptr[k + 1] > ptr[k]) sr(&sbuf[ptr[k]], &rbuf[ptr[k]], ptr[k + 1] - ptr[k], part.neighbour_rank[k], user);
+      // per shared dof, walk the neighbours in ascending rank order; the own value joins before the first higher-ranked neighbour
+      Vec acc(n, 0.0); std::vector<char> seen(n, 0), own_added(n, 0);
+      const Vec v0 = v;
+      for (int k = 0; k < nn; ++k) {
+        const bool self_before = part.rank < part.neighbour_rank[k];
+        for (int64_t j = ptr[k]; j < ptr[k + 1]; ++j) { const int32_t i = dof[j];
+          if (self_before && !own_added[i]) { acc[i] += v0[i]; own_added[i] = 1; }
+          acc[i] += rbuf[j]; seen[i] = 1; }
+      }
+      for (int64_t i = 0; i < n; ++i) if (seen[i]) { if (!own_added[i]) acc[i] += v0[i]; v[i] = acc[i]; }
+      return;
+    }
+    Vec rbuf(plane);
     if (part.has_upper) { sr(&v[n - plane], rbuf.data(), plane, part.rank + 1, user); for (int64_t i = 0; i < plane; ++i) v[n - plane + i] += rbuf[i]; }
     if (part.has_lower) { sr(&v[0], rbuf.data(), plane, part.rank - 1, user); for (int64_t i = 0; i < plane; ++i) v[i] += rbuf[i]; }
   }
+  int64_t owned(int64_t n, int64_t plane) const {
+    if (!multi()) return n;
+    if (general()) return n == n_u ? part.n_owned_u : part.n_owned_p;
+    return part.has_upper ? n - plane : n;                               // a shared plane is counted by its upper owner
+  }
   double dot(const Vec &a, const Vec &b, int64_t plane) const {
-    int64_t n = (int64_t)a.size(); if (multi() && part.has_upper) n -= plane;  // shared plane counted by its upper owner
+    const int64_t n = owned((int64_t)a.size(), plane);
     double s = 0; for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
     if (multi()) ar(&s, 1, user);
     return s;
@@ -282,7 +308,7 @@ struct Oracle {
     bfc.assign(d.bface_cell, d.bface_cell + d.n_bfaces); bfl.assign(d.bface_local, d.bface_local + d.n_bfaces); bfi.assign(d.bface_id, d.bface_id + d.n_bfaces);
     ddof.assign(d.dirichlet_dof, d.dirichlet_dof + d.n_dirichlet); dval.assign(d.dirichlet_value, d.dirichlet_value + d.n_dirichlet);
     nlab.assign(d.neumann_label, d.neumann_label + d.n_neumann); ncomp.assign(d.neumann_component, d.neumann_component + d.n_neumann); nval.assign(d.neumann_value, d.neumann_value + d.n_neumann);
-    mat = d.mat; comm.part = d.part;
+    mat = d.mat; comm.part = d.part; comm.n_u = d.n_dofs_u;
     cons_u.init(d.cons_u); cons_p.init(d.cons_p);
     is_pdir.assign(d.n_dofs_p, 0); pdir_val.assign(d.n_dofs_p, 0.0); any_pdir = d.n_dirichlet_p > 0;
     for (int64_t i = 0; i < d.n_dirichlet_p; ++i) { is_pdir[d.dirichlet_dof_p[i]] = 1; pdir_val[d.dirichlet_dof_p[i]] = d.dirichlet_value_p[i]; }

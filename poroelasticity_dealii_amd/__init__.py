@@ -23,6 +23,7 @@ VEC_STRAIN0, VEC_PROJ_RHS0, VEC_DIAG_U, VEC_STRESS0 = 16, 32, 48, 64
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
 
 
 class FeTables(C.Structure):
@@ -39,7 +40,9 @@ class Structured(C.Structure):
 
 
 class Partition(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("n_ranks", C.c_int32), ("has_lower", C.c_int32), ("has_upper", C.c_int32), ("plane_u", C.c_int64), ("plane_p", C.c_int64)]
+    _fields_ = [("rank", C.c_int32), ("n_ranks", C.c_int32), ("has_lower", C.c_int32), ("has_upper", C.c_int32), ("plane_u", C.c_int64), ("plane_p", C.c_int64),
+                ("n_neighbours", C.c_int32), ("neighbour_rank", _ip), ("shared_ptr_u", _lp), ("shared_dof_u", _ip), ("shared_ptr_p", _lp), ("shared_dof_p", _ip),
+                ("n_owned_u", C.c_int64), ("n_owned_p", C.c_int64)]
 
 
 class Constraints(C.Structure):
@@ -162,6 +165,10 @@ def load_host():
         L.poro_host_build_gmsh.restype = C.c_void_p
         L.poro_host_build_gmsh.argtypes = [C.c_char_p, C.c_int] + bc
         L.poro_host_set_pressure_bc.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
+        L.poro_host_partition.restype = C.c_void_p
+        L.poro_host_partition.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.poro_host_local_to_global.restype = C.c_int64
+        L.poro_host_local_to_global.argtypes = [C.c_void_p, C.c_int, _ip]
         L.poro_host_desc.restype = C.POINTER(Desc)
         L.poro_host_desc.argtypes = [C.c_void_p]
         L.poro_host_free.argtypes = [C.c_void_p]
@@ -243,6 +250,20 @@ class Problem:
     def gmsh(cls, path, degree_u, material, dirichlet, neumann=()):
         keep, args = cls._bc(dirichlet, neumann)
         return cls(load_host().poro_host_build_gmsh(path.encode(), degree_u, *args, C.byref(material)))
+
+    def partition(self, rank, n_ranks):
+        """piece `rank` of a general partition of this (global) problem: contiguous ranges of the cells in Morton order + interface lists
+        (poro_partition.n_neighbours > 0); .local_to_global_u / _p map the piece's dofs back"""
+        H = load_host()
+        h = H.poro_host_partition(self.handle, rank, n_ranks)
+        if not h:
+            raise RuntimeError(H.poro_host_last_error().decode())
+        P = type(self)(h)
+        for name, space in (("local_to_global_u", 0), ("local_to_global_p", 1)):
+            a = np.zeros(H.poro_host_local_to_global(h, space, None), dtype=np.int32)
+            H.poro_host_local_to_global(h, space, a.ctypes.data_as(_ip))
+            setattr(P, name, a)
+        return P
 
     def set_pressure_bc(self, conditions):
         """extension (the reference has no pressure boundary conditions): prescribed pressure [(boundary label, value)], e.g. a drained face p = 0"""

@@ -101,8 +101,18 @@ struct ConsDev {
 
 struct Timer { double seconds = 0; int64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
 
+// interface of a general partition in one dof space (poro_partition.shared_*): concatenated per-neighbour lists for packing / receiving, and per
+// shared dof the sources of its sum in ascending rank order (-1 = this rank's own partial value, otherwise a position in `recv`)
+struct IfcDev {
+  int64_t m_send = 0, m_shared = 0, n_owned = 0;
+  std::vector<int64_t> ptr;                 // [n_neighbours + 1] into dof / send / recv
+  DevBuf<int32_t> dof, sh_dof, sh_src; DevBuf<int64_t> sh_ptr; DevBuf<double> send, recv;
+  std::vector<double> hsend, hrecv;         // host staging of the callback communicator
+};
+
 struct Comm {
   poro_partition part{};
+  bool general = false; std::vector<int32_t> neighbours; IfcDev ifc_u, ifc_p;
   // RCCL (resolved at run time from librccl.so.1)
   void *nccl_comm = nullptr;
   // host-staged callbacks (tests)
@@ -184,6 +194,8 @@ void la_csr_residual(hipStream_t s, const CsrDev &A, const double *M, const doub
                      const double *src, double *R);
 void la_pressure_tmp(hipStream_t s, double *t, const double *ev, const double *ev0, const double *p, const double *p_old, double c1, double c2, int64_t n);
 void la_jacobian(hipStream_t s, double *J, const double *M, const double *K, double a, double kappa, int64_t nnz);
+void la_ifc_pack(hipStream_t s, const IfcDev &I, const double *v);
+void la_ifc_sum(hipStream_t s, const IfcDev &I, double *v);
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag);
 void la_reciprocal(hipStream_t s, double *y, const double *x, int64_t n);
 void la_pointwise_mul(hipStream_t s, double *y, const double *x, int64_t n);   // y *= x

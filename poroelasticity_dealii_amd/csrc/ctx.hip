@@ -143,10 +143,71 @@ struct EventPair {
 };
 
 // ---- communication: sum the neighbour's partial rows on the shared node planes; all-reduce scalars -------------------
+// general partition: per-neighbour interface lists (poro_partition.shared_*).  One pack kernel, one grouped exchange with all neighbours, one kernel
+// that sums own + received partial rows in ascending rank order.
+void build_interface(poro_ctx *c, IfcDev &I, const int64_t *ptr, const int32_t *dof, int64_t n, int64_t n_owned) {
+  const poro_partition &pt = c->comm.part; const int nn = pt.n_neighbours;
+  if (!ptr || (ptr[nn] > 0 && !dof)) throw Error("poro_partition: interface lists missing");
+  if (n_owned < 0 || n_owned > n) throw Error("poro_partition: n_owned out of range");
+  I.n_owned = n_owned; I.ptr.assign(ptr, ptr + nn + 1); I.m_send = ptr[nn];
+  if (ptr[0] != 0) throw Error("poro_partition: shared_ptr must start at 0");
+  std::vector<std::vector<int32_t>> src(n);          // per local dof: sources in ascending rank order
+  std::vector<char> own_in(n, 0);
+  for (int k = 0; k < nn; ++k) {
+    if (ptr[k + 1] < ptr[k]) throw Error("poro_partition: shared_ptr not monotone");
+    const bool self_before = pt.rank < pt.neighbour_rank[k];
+    for (int64_t j = ptr[k]; j < ptr[k + 1]; ++j) {
+      const int32_t i = dof[j]; if (i < 0 || i >= n) throw Error("poro_partition: shared dof out of range");
+      if (self_before && !own_in[i]) { src[i].push_back(-1); own_in[i] = 1; }
+      src[i].push_back((int32_t)j);
+    }
+  }
+  std::vector<int32_t> sh_dof, sh_src; std::vector<int64_t> sh_ptr{0};
+  for (int64_t i = 0; i < n; ++i) if (!src[i].empty()) {
+    if (!own_in[i]) src[i].push_back(-1);
+    sh_dof.push_back((int32_t)i); sh_src.insert(sh_src.end(), src[i].begin(), src[i].end()); sh_ptr.push_back((int64_t)sh_src.size());
+  }
+  I.m_shared = (int64_t)sh_dof.size();
+  if (I.m_send) { I.dof.upload(std::vector<int32_t>(dof, dof + I.m_send)); I.send.alloc(I.m_send); I.recv.alloc(I.m_send); I.hsend.resize(I.m_send); I.hrecv.resize(I.m_send); }
+  if (I.m_shared) { I.sh_dof.upload(sh_dof); I.sh_src.upload(sh_src); I.sh_ptr.upload(sh_ptr); }
+}
+void setup_general_partition(poro_ctx *c, const poro_desc *d) {
+  Comm &cm = c->comm; const poro_partition &pt = cm.part;
+  if (pt.n_neighbours <= 0) return;
+  if (pt.n_ranks < 2) throw Error("poro_partition: neighbours on a single rank");
+  if (!pt.neighbour_rank) throw Error("poro_partition: neighbour_rank missing");
+  for (int k = 0; k < pt.n_neighbours; ++k) {
+    const int q = pt.neighbour_rank[k];
+    if (q < 0 || q >= pt.n_ranks || q == pt.rank || (k && q <= pt.neighbour_rank[k - 1])) throw Error("poro_partition: neighbour_rank must be ascending, in range and without the own rank");
+  }
+  cm.general = true; cm.neighbours.assign(pt.neighbour_rank, pt.neighbour_rank + pt.n_neighbours);
+  build_interface(c, cm.ifc_u, pt.shared_ptr_u, pt.shared_dof_u, d->n_dofs_u, pt.n_owned_u);
+  build_interface(c, cm.ifc_p, pt.shared_ptr_p, pt.shared_dof_p, d->n_dofs_p, pt.n_owned_p);
+  if (c->dim > 1 && pt.n_owned_u % c->dim) throw Error("poro_partition: n_owned_u must hold whole displacement nodes");
+}
+void exchange_add_general(poro_ctx *c, double *v, int64_t n) {
+  Comm &cm = c->comm; IfcDev &I = n == c->n_u ? cm.ifc_u : cm.ifc_p;
+  if (!I.m_send) return;
+  const int nn = (int)cm.neighbours.size();
+  la_ifc_pack(c->stream, I, v);
+  if (cm.nccl_comm) {
+    ncclComm_t comm = (ncclComm_t)cm.nccl_comm;
+    PORO_NCCL(g_rccl.GroupStart());
+    for (int k = 0; k < nn; ++k) { const int64_t m = I.ptr[k + 1] - I.ptr[k]; if (!m) continue;
+      PORO_NCCL(g_rccl.Send(I.send.p + I.ptr[k], m, ncclFloat64, cm.neighbours[k], comm, c->stream)); PORO_NCCL(g_rccl.Recv(I.recv.p + I.ptr[k], m, ncclFloat64, cm.neighbours[k], comm, c->stream)); }
+    PORO_NCCL(g_rccl.GroupEnd());
+  } else if (cm.sr) {
+    PORO_HIP(hipMemcpyAsync(I.hsend.data(), I.send.p, I.m_send * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < nn; ++k) { const int64_t m = I.ptr[k + 1] - I.ptr[k]; if (m) cm.sr(I.hsend.data() + I.ptr[k], I.hrecv.data() + I.ptr[k], m, cm.neighbours[k], cm.user); }
+    PORO_HIP(hipMemcpyAsync(I.recv.p, I.hrecv.data(), I.m_send * sizeof(double), hipMemcpyHostToDevice, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+  } else throw Error("partitioned context without a communicator (call poro_ctx_comm_init_* first)");
+  la_ifc_sum(c->stream, I, v);
+}
 void exchange_add(poro_ctx *c, double *v, int64_t n, int64_t plane) {
   Comm &cm = c->comm;
   if (!cm.multi()) return;
   Timed tm(c, "halo_exchange");
+  if (cm.general) { exchange_add_general(c, v, n); return; }
   if (cm.recv_lo.n < (size_t)plane) { cm.recv_lo.alloc(plane); cm.recv_hi.alloc(plane); }
   if (cm.nccl_comm) {
     ncclComm_t comm = (ncclComm_t)cm.nccl_comm;
@@ -180,7 +241,10 @@ void allreduce_sum(poro_ctx *c, double *dev, int n) {
     PORO_HIP(hipMemcpyAsync(dev, h, n * sizeof(double), hipMemcpyHostToDevice, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
   } else throw Error("partitioned context without a communicator");
 }
-int64_t owned(poro_ctx *c, int64_t n, int64_t plane) { return (c->comm.multi() && c->comm.part.has_upper) ? n - plane : n; }
+int64_t owned(poro_ctx *c, int64_t n, int64_t plane) {
+  if (c->comm.general) return n == c->n_u ? c->comm.ifc_u.n_owned : c->comm.ifc_p.n_owned;
+  return (c->comm.multi() && c->comm.part.has_upper) ? n - plane : n;
+}
 
 AsmArgs asm_args(poro_ctx *c) {
   AsmArgs a{};
@@ -711,7 +775,9 @@ void setup(poro_ctx *c, const poro_desc *d) {
   { bool inter = true;     // node-interleaved displacement numbering?
     for (int64_t i = 0; i < c->n_cells * c->ns_u && inter; ++i) { const int32_t b = d->cell_dofs_u[i * c->dim]; if (b % c->dim) inter = false; for (int k = 1; k < c->dim && inter; ++k) if (d->cell_dofs_u[i * c->dim + k] != b + k) inter = false; }
     c->interleaved_u = inter ? 1 : 0; }
-  if (c->operator_mode == PORO_OP_MATRIX_FREE && !d->box.enabled && d->part.n_ranks > 1) throw Error("the matrix-free operator on a general (non-box) mesh is implemented for one rank");
+  if (d->part.n_neighbours > 0 && d->box.enabled) throw Error("a general partition (poro_partition.n_neighbours > 0) carries no box tag: pieces are not boxes");
+  if (!d->box.enabled && d->part.n_ranks > 1 && d->part.n_neighbours <= 0) throw Error("a partitioned general mesh needs the interface lists of poro_partition (n_neighbours > 0)");
+  setup_general_partition(c, d);
   if (d->box.enabled) {
     // the lexicographic numbering the structured kernels assume must be the caller's numbering (spot-checked on three cells)
     int64_t nn[3] = {1, 1, 1}, np[3] = {1, 1, 1}, ncells = 1;

@@ -473,6 +473,25 @@ void la_cons_reduce(hipStream_t s, const ConsDev &C, double *y) {
   if (C.n_masters) hipLaunchKernelGGL(k_cons_gather, (unsigned)((C.n_masters + kBlock - 1) / kBlock), kBlock, 0, s, C.n_masters, C.t_master.p, C.t_ptr.p, C.t_dof.p, C.t_weight.p, y);
   hipLaunchKernelGGL(k_cons_zero, (unsigned)((C.n + kBlock - 1) / kBlock), kBlock, 0, s, C.n, C.dof.p, y);
 }
+// general partition: pack the shared entries for the neighbours; sum the received partial rows in ascending rank order (src < 0: the own value)
+__global__ void k_ifc_pack(int64_t m, const int32_t *__restrict__ dof, const double *__restrict__ v, double *__restrict__ send) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < m) send[j] = v[dof[j]];
+}
+__global__ void k_ifc_sum(int64_t m, const int32_t *__restrict__ sh_dof, const int64_t *__restrict__ sh_ptr, const int32_t *__restrict__ sh_src, const double *__restrict__ recv, double *v) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const int32_t dof = sh_dof[i]; const double own = v[dof];
+  double acc = 0;
+  for (int64_t k = sh_ptr[i]; k < sh_ptr[i + 1]; ++k) { const int32_t src = sh_src[k]; acc += src < 0 ? own : recv[src]; }
+  v[dof] = acc;
+}
+void la_ifc_pack(hipStream_t s, const IfcDev &I, const double *v) {
+  if (I.m_send) hipLaunchKernelGGL(k_ifc_pack, (unsigned)((I.m_send + kBlock - 1) / kBlock), kBlock, 0, s, I.m_send, I.dof.p, v, I.send.p);
+}
+void la_ifc_sum(hipStream_t s, const IfcDev &I, double *v) {
+  if (I.m_shared) hipLaunchKernelGGL(k_ifc_sum, (unsigned)((I.m_shared + kBlock - 1) / kBlock), kBlock, 0, s, I.m_shared, I.sh_dof.p, I.sh_ptr.p, I.sh_src.p, I.recv.p, v);
+}
 void la_csr_diag(hipStream_t s, const CsrDev &A, const double *val, double *diag) {
   hipLaunchKernelGGL(k_csr_diag, grid_for(A.n), kBlock, 0, s, A.n, A.diag_pos.p, val, diag);
 }

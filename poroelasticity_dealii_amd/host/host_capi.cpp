@@ -64,6 +64,18 @@ void *poro_host_build_gmsh(const char *path, int k_u,
   } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 
+// piece `rank` of a general n_ranks partition of a global problem (Morton cell ranges + interface lists); the global problem stays valid
+void *poro_host_partition(void *global, int rank, int n_ranks) {
+  try { auto *L = new ProblemData(); try { partition_problem(*static_cast<ProblemData *>(global), rank, n_ranks, *L); } catch (...) { delete L; throw; } return L; }
+  catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+// local -> global dof map of a piece (space 0: displacement, 1: pressure); returns the length, copies when out != NULL
+int64_t poro_host_local_to_global(void *h, int space, int32_t *out) {
+  auto &v = space == 0 ? static_cast<ProblemData *>(h)->local_to_global_u : static_cast<ProblemData *>(h)->local_to_global_p;
+  if (out) std::memcpy(out, v.data(), v.size() * sizeof(int32_t));
+  return (int64_t)v.size();
+}
+
 // extension: prescribed pressures on boundary labels (before the context is created)
 int poro_host_set_pressure_bc(void *h, int n, const int32_t *labels, const double *values) {
   try {

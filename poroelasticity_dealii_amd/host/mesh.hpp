@@ -334,6 +334,10 @@ struct ProblemData {
   std::vector<int32_t> dirichlet_dof_p; std::vector<double> dirichlet_value_p;
   poro_material mat{}; poro_partition part{};
   ConstraintList cons_u, cons_p;      // hanging-node constraints (locally refined meshes)
+  // general partition (partition_problem): interface lists and the local -> global maps of the piece
+  std::vector<int32_t> part_neighbours, part_shared_u, part_shared_p, local_to_global_u, local_to_global_p;
+  std::vector<int64_t> part_ptr_u, part_ptr_p;
+  bool dirichlet_given = false;       // the Dirichlet list was filled by the caller (pieces of a partition: from the global list)
   poro_desc d{};
 
   // ConstraintMatrix semantics of PoroElasticDisplacementSolver.h:112-136: hanging-node constraints first, boundary values only for dofs that are
@@ -359,7 +363,7 @@ struct ProblemData {
   void finalize(int k_u, bool have_dofs = false) {
     if (!have_dofs) dofs = distribute_dofs(mesh, k_u);
     fe.build(mesh.dim, k_u);
-    make_dirichlet(mesh, dofs, bc, dirichlet_dof, dirichlet_value);
+    if (!dirichlet_given) make_dirichlet(mesh, dofs, bc, dirichlet_dof, dirichlet_value);
     close_constraints();
     d = poro_desc{};
     d.abi_version = PORO_ABI_VERSION; d.dim = mesh.dim; d.degree_u = k_u; d.degree_p = 1;
@@ -374,12 +378,15 @@ struct ProblemData {
     d.neumann_label = bc.neumann_labels.data(); d.neumann_component = bc.neumann_components.data(); d.neumann_value = bc.neumann_values.data();
     d.mat = mat; d.box = mesh.box;
     if (part.n_ranks == 0) { part.n_ranks = 1; part.rank = 0; }
+    part.n_neighbours = (int32_t)part_neighbours.size();
+    part.neighbour_rank = part_neighbours.data(); part.shared_ptr_u = part_ptr_u.data(); part.shared_dof_u = part_shared_u.data();
+    part.shared_ptr_p = part_ptr_p.data(); part.shared_dof_p = part_shared_p.data();
     d.part = part;
     d.cons_u = cons_u.c_view(); d.cons_p = cons_p.c_view();
     set_pressure_bc();
   }
   void set_pressure_bc() {
-    make_dirichlet_p(mesh, dofs, bc, dirichlet_dof_p, dirichlet_value_p);
+    if (!dirichlet_given) make_dirichlet_p(mesh, dofs, bc, dirichlet_dof_p, dirichlet_value_p);
     d.n_dirichlet_p = (int64_t)dirichlet_dof_p.size(); d.dirichlet_dof_p = dirichlet_dof_p.data(); d.dirichlet_value_p = dirichlet_value_p.data();
   }
 };
@@ -417,6 +424,95 @@ inline void build_refined_box_problem(ProblemData &P, int dim, const int n[3], c
   P.mesh = std::move(R.mesh); P.dofs = std::move(R.dofs); P.cons_u = std::move(R.cons_u); P.cons_p = std::move(R.cons_p);
   P.part = poro_partition{}; P.part.n_ranks = 1;
   P.finalize(k_u, true);
+}
+
+// ---- general partition (last sentence): contiguous ranges of the cells in Morton order + indexed interface lists --------------
+// Works on any global ProblemData (Gmsh mesh, box, graded box): rank r gets the cells of its range as a standalone mesh.  Local numbering: the
+// dofs this rank owns first (owner = the highest rank touching the dof, as the upper slab owns a shared plane), each group in ascending global
+// order, which keeps the components of a displacement node adjacent.  Pressure dofs and vertices coincide in this provider, so the local vertex
+// numbering is the local pressure numbering.
+inline std::vector<int64_t> morton_cell_order(const Mesh &m) {
+  const int dim = m.dim, nv = 1 << dim; const int64_t nc = m.n_cells();
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int64_t v = 0; v < m.n_vertices(); ++v) for (int d = 0; d < dim; ++d) { lo[d] = std::min(lo[d], m.vertices[v * dim + d]); hi[d] = std::max(hi[d], m.vertices[v * dim + d]); }
+  std::vector<std::pair<uint64_t, int64_t>> key(nc);
+  for (int64_t c = 0; c < nc; ++c) {
+    uint64_t q[3] = {0, 0, 0};
+    for (int d = 0; d < dim; ++d) {
+      double x = 0; for (int v = 0; v < nv; ++v) x += m.vertices[(int64_t)m.cells[c * nv + v] * dim + d];
+      x = (x / nv - lo[d]) / std::max(hi[d] - lo[d], 1e-300);
+      q[d] = (uint64_t)std::min(1023.0, std::max(0.0, std::floor(x * 1024.0)));
+    }
+    uint64_t k = 0;
+    for (int b = 9; b >= 0; --b) for (int d = dim - 1; d >= 0; --d) k = (k << 1) | ((q[d] >> b) & 1);
+    key[c] = {k, c};
+  }
+  std::sort(key.begin(), key.end());
+  std::vector<int64_t> order(nc); for (int64_t i = 0; i < nc; ++i) order[i] = key[i].second;
+  return order;
+}
+
+inline void partition_problem(const ProblemData &G, int rank, int n_ranks, ProblemData &L) {
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::runtime_error("partition_problem: bad rank / n_ranks");
+  if (G.part.n_ranks > 1) throw std::runtime_error("partition_problem: the problem is already a piece of a partition");
+  if (G.cons_u.n() || G.cons_p.n()) throw std::runtime_error("partition_problem: meshes with hanging-node constraints are not partitioned");
+  if (!G.dirichlet_dof_p.empty()) throw std::runtime_error("partition_problem: prescribed pressures are implemented for one rank");
+  const Mesh &gm = G.mesh; const int dim = gm.dim, nv = 1 << dim, k_u = G.dofs.k_u, dpc = ipow(k_u + 1, dim) * dim; const int64_t nc = gm.n_cells();
+  if (nc < n_ranks) throw std::runtime_error("partition_problem: fewer cells than ranks");
+  const std::vector<int64_t> order = morton_cell_order(gm);
+  std::vector<int32_t> cell_rank(nc);
+  for (int r = 0; r < n_ranks; ++r) { int c0, c1; slab_range((int)nc, r, n_ranks, c0, c1); for (int i = c0; i < c1; ++i) cell_rank[order[i]] = r; }
+  // ranks touching every dof (sorted, unique)
+  auto touching = [&](const std::vector<int32_t> &cell_dofs, int per_cell, int64_t n) {
+    std::vector<std::vector<int32_t>> t(n);
+    for (int64_t c = 0; c < nc; ++c) for (int k = 0; k < per_cell; ++k) { auto &v = t[cell_dofs[c * per_cell + k]]; if (std::find(v.begin(), v.end(), cell_rank[c]) == v.end()) v.push_back(cell_rank[c]); }
+    for (auto &v : t) std::sort(v.begin(), v.end());
+    return t;
+  };
+  const auto tu = touching(G.dofs.cell_u, dpc, G.dofs.n_u), tp = touching(G.dofs.cell_p, nv, G.dofs.n_p);
+  auto has = [&](const std::vector<int32_t> &v) { return std::binary_search(v.begin(), v.end(), (int32_t)rank); };
+  // local numbering: owned first, each group ascending in the global index
+  auto number = [&](const std::vector<std::vector<int32_t>> &t, std::vector<int32_t> &l2g, std::vector<int32_t> &g2l, int64_t &n_owned) {
+    g2l.assign(t.size(), -1); l2g.clear();
+    for (size_t g = 0; g < t.size(); ++g) if (has(t[g]) && t[g].back() == rank) { g2l[g] = (int32_t)l2g.size(); l2g.push_back((int32_t)g); }
+    n_owned = (int64_t)l2g.size();
+    for (size_t g = 0; g < t.size(); ++g) if (has(t[g]) && t[g].back() != rank) { g2l[g] = (int32_t)l2g.size(); l2g.push_back((int32_t)g); }
+  };
+  std::vector<int32_t> g2l_u, g2l_p; int64_t own_u = 0, own_p = 0;
+  number(tu, L.local_to_global_u, g2l_u, own_u); number(tp, L.local_to_global_p, g2l_p, own_p);
+  // interface lists: for every other rank q the dofs both touch, ascending global index
+  std::map<int32_t, std::vector<int32_t>> su, sp;
+  for (size_t g = 0; g < tu.size(); ++g) if (has(tu[g])) for (int32_t q : tu[g]) if (q != rank) su[q].push_back(g2l_u[g]);
+  for (size_t g = 0; g < tp.size(); ++g) if (has(tp[g])) for (int32_t q : tp[g]) if (q != rank) sp[q].push_back(g2l_p[g]);
+  for (auto &kv : su) sp[kv.first];       // same neighbour set for both spaces (pressure lists may be empty)
+  for (auto &kv : sp) su[kv.first];
+  L.part_neighbours.clear(); L.part_ptr_u.assign(1, 0); L.part_ptr_p.assign(1, 0); L.part_shared_u.clear(); L.part_shared_p.clear();
+  for (auto &kv : su) {
+    L.part_neighbours.push_back(kv.first);
+    L.part_shared_u.insert(L.part_shared_u.end(), kv.second.begin(), kv.second.end()); L.part_ptr_u.push_back((int64_t)L.part_shared_u.size());
+    const auto &vp = sp[kv.first]; L.part_shared_p.insert(L.part_shared_p.end(), vp.begin(), vp.end()); L.part_ptr_p.push_back((int64_t)L.part_shared_p.size());
+  }
+  // the piece as a standalone mesh
+  Mesh &m = L.mesh; m = Mesh{}; m.dim = dim;
+  m.vertices.resize(L.local_to_global_p.size() * dim);
+  for (size_t v = 0; v < L.local_to_global_p.size(); ++v) for (int d = 0; d < dim; ++d) m.vertices[v * dim + d] = gm.vertices[(int64_t)L.local_to_global_p[v] * dim + d];
+  std::vector<int32_t> local_cell(nc, -1); int32_t nl = 0;
+  L.dofs = DoFs{}; L.dofs.k_u = k_u; L.dofs.n_u = (int64_t)L.local_to_global_u.size(); L.dofs.n_p = (int64_t)L.local_to_global_p.size();
+  for (int64_t i = 0; i < nc; ++i) { const int64_t c = order[i]; if (cell_rank[c] != rank) continue;    // local cells keep the Morton order
+    local_cell[c] = nl++;
+    for (int v = 0; v < nv; ++v) { m.cells.push_back(g2l_p[gm.cells[c * nv + v]]); L.dofs.cell_p.push_back(g2l_p[G.dofs.cell_p[c * nv + v]]); }
+    for (int k = 0; k < dpc; ++k) L.dofs.cell_u.push_back(g2l_u[G.dofs.cell_u[c * dpc + k]]);
+  }
+  for (size_t f = 0; f < gm.bface_cell.size(); ++f) if (cell_rank[gm.bface_cell[f]] == rank) { m.bface_cell.push_back(local_cell[gm.bface_cell[f]]); m.bface_local.push_back(gm.bface_local[f]); m.bface_id.push_back(gm.bface_id[f]); }
+  // boundary values from the GLOBAL closed list: a local dof can sit on the boundary without any local boundary face
+  L.dirichlet_dof.clear(); L.dirichlet_value.clear(); L.dirichlet_given = true;
+  { std::vector<std::pair<int32_t, double>> dl;
+    for (size_t i = 0; i < G.dirichlet_dof.size(); ++i) if (g2l_u[G.dirichlet_dof[i]] >= 0) dl.emplace_back(g2l_u[G.dirichlet_dof[i]], G.dirichlet_value[i]);
+    std::sort(dl.begin(), dl.end());
+    for (auto &kv : dl) { L.dirichlet_dof.push_back(kv.first); L.dirichlet_value.push_back(kv.second); } }
+  L.bc = G.bc; L.mat = G.mat;
+  L.part = poro_partition{}; L.part.rank = rank; L.part.n_ranks = n_ranks; L.part.n_owned_u = own_u; L.part.n_owned_p = own_p;
+  L.finalize(k_u, true);
 }
 
 }  // namespace poro_host

@@ -1,0 +1,95 @@
+"""General partition (last sentence): contiguous ranges of the cells in Morton order + indexed interface lists, for meshes that are not boxes
+(the Gmsh mesh of read_mesh(), PoroelasticityFSS.h:438-445) - N ranks over gloo, each running the oracle on its piece through the same descriptors and
+callback communicator the HIP library takes, reproduce the single-rank result.  Also the host provider's bookkeeping on its own."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import poroelasticity_dealii_amd as pk
+import oracle_py
+from common import REF
+from test_multirank_cpu import HERE, free_port
+
+
+def run_ranks(tmp_path, world, mesh, deg, backend):
+    port = free_port()
+    outs = [str(tmp_path / f"g{r}.npz") for r in range(world)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mr_general_worker.py"), str(r), str(world), str(port), mesh, str(deg), outs[r], backend], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    return [np.load(o) for o in outs]
+
+
+def assemble_global(R, key, l2g, n):
+    """global vector from the pieces; every copy of a shared entry must be BITWISE the same (sums in ascending rank order on every rank)"""
+    out = np.full(n, np.nan)
+    for r in R:
+        idx = r[l2g]; have = ~np.isnan(out[idx])
+        assert np.array_equal(out[idx][have], r[key][have]), key
+        out[idx] = r[key]
+    assert not np.isnan(out).any()
+    return out
+
+
+def check_against_single_rank(R, mesh, deg, tol_u=1e-9):
+    from mr_general_worker import global_problem
+    P = global_problem(mesh, deg)
+    O = oracle_py.Oracle(P, hoisted=True)
+    try:
+        tr, _ = O.run(1, REF["p_init"], REF["dt"], max_it=20000, prec=oracle_py.PREC_JACOBI)
+        nu, n_p = P.desc.n_dofs_u, P.desc.n_dofs_p
+        assert sum(int(r["owned"][0]) for r in R) == nu and sum(int(r["owned"][1]) for r in R) == n_p      # every dof has exactly one owner
+        for r in R:
+            assert np.array_equal(r["trace"][1:, :3], tr[1:, :3])
+        u = assemble_global(R, "u", "l2g_u", nu); p = assemble_global(R, "p", "l2g_p", n_p)
+        rhs = assemble_global(R, "rhs_u", "l2g_u", nu); Ax = assemble_global(R, "Ax", "l2g_u", nu); ev = assemble_global(R, "epsv", "l2g_p", n_p)
+        y = O.apply(pk.MAT_A_U, np.sin(0.11 * np.arange(nu)))
+        assert np.abs(Ax - y).max() <= 1e-12 * np.abs(y).max()
+        assert np.linalg.norm(rhs - O.get(pk.VEC_RHS_U)) <= 1e-9 * np.linalg.norm(rhs)
+        assert np.linalg.norm(u - O.get(pk.VEC_U)) <= tol_u * np.linalg.norm(u)
+        assert np.linalg.norm(p - O.get(pk.VEC_P)) <= 1e-10 * np.linalg.norm(p)
+        assert np.linalg.norm(ev - O.get(pk.VEC_EPSV)) <= 1e-6 * np.linalg.norm(ev)
+    finally:
+        O.close(); P.close()
+
+
+@pytest.mark.parametrize("world,mesh,deg", [(2, "gmsh", 2), (3, "gmsh", 1), (4, "box:4,4,4", 1), (3, "box:5,6", 2)])
+def test_general_partition_time_step_equals_single_rank(tmp_path, world, mesh, deg):
+    R = run_ranks(tmp_path, world, mesh, deg, "oracle")
+    if world > 2:
+        assert max(len(r["neighbours"]) for r in R) >= 2           # some rank talks to more than one neighbour (dofs shared by 3+ ranks exist on these meshes)
+    check_against_single_rank(R, mesh, deg)
+
+
+def test_partition_bookkeeping():
+    """pieces of the Gmsh mesh: cells are split exactly, interface lists are symmetric and in the same (global) order on both sides, owned dofs come first"""
+    from mr_general_worker import global_problem
+    PG = global_problem("gmsh", 2)
+    world = 3
+    pieces = [PG.partition(r, world) for r in range(world)]
+    try:
+        assert sum(P.desc.n_cells for P in pieces) == PG.desc.n_cells
+        owner_u = np.full(PG.desc.n_dofs_u, -1)
+        for r, P in enumerate(pieces):
+            pt = P.desc.part
+            assert pt.rank == r and pt.n_ranks == world and pt.n_neighbours > 0 and not P.desc.box.enabled
+            own = P.local_to_global_u[:pt.n_owned_u]
+            assert np.all(owner_u[own] == -1); owner_u[own] = r
+            assert np.all(np.diff(own) > 0) and np.all(np.diff(P.local_to_global_u[pt.n_owned_u:]) > 0)
+            for k in range(pt.n_neighbours):
+                q = pt.neighbour_rank[k]; Q = pieces[q]; qt = Q.desc.part
+                kq = [qt.neighbour_rank[j] for j in range(qt.n_neighbours)].index(r)
+                mine = P.local_to_global_u[[pt.shared_dof_u[j] for j in range(pt.shared_ptr_u[k], pt.shared_ptr_u[k + 1])]]
+                theirs = Q.local_to_global_u[[qt.shared_dof_u[j] for j in range(qt.shared_ptr_u[kq], qt.shared_ptr_u[kq + 1])]]
+                assert np.array_equal(mine, theirs) and len(mine) > 0
+        assert np.all(owner_u >= 0)
+        with pytest.raises(RuntimeError, match="already a piece"):
+            pieces[0].partition(0, 2)
+    finally:
+        for P in pieces:
+            P.close()
+        PG.close()
