@@ -21,6 +21,7 @@
 // k_kron_fix_constrained.
 #include "common.hpp"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 namespace poro {
 namespace {
@@ -44,7 +45,7 @@ struct KronConsts {
   double cc_mx[4];                             // c1..c4 * sC sMx sC   (O_y / D_y of oz / wz  -> XM)
 };
 struct KronArgs {
-  int nn[3]; int n64, nty64, has32, nty32, x0_32, nzc, zunit, zq, zr, nA, nblocks;   // z-chunk zc owns zq (+1 if zc < zr) units of zunit planes, the last one also the tail; nA = workgroups with 64-lane tiles
+  int nn[3]; int n64, nty64, has32, nty32, x0_32, nzc, zunit, zq, zr, nA, nblocks, cols, zmajor;   // z-chunk zc owns zq (+1 if zc < zr) units of zunit planes, the last one also the tail; nA = workgroups with 64-lane tiles
   KronConsts k;
   const uint8_t *nodemask; int constrained, mask_anywhere;
   double *dot_partials;   // optional: per-workgroup partial of x.y over the free rows (x is zero on the Dirichlet columns after masking)
@@ -55,6 +56,16 @@ struct KronArgs {
 __device__ inline int64_t xcd_remap(int64_t bid, int64_t n) {
   const int64_t q = n / 8, r = n % 8, xcd = bid % 8, idx = bid / 8;
   return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+// workgroup -> (tile column, z-chunk).  The hardware deals workgroups to the 8 XCDs round-robin; xcd_remap gives every XCD a contiguous range of
+// tile numbers.  z-major numbering puts all columns of ONE z-chunk on one XCD (cols = 32, nzc = 8 at 72^3): x- and y-neighbours march in lockstep
+// through the same planes and find each other's halo rows / lines in that XCD's L2.  (Column-major numbering shares only among 4 y-neighbours.)
+__device__ inline void tile_of(const KronArgs &a, int &col, int &zc) {
+  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
+  if (a.zmajor) { zc = tile / a.cols; col = tile % a.cols; }
+  else if (tile < a.nA) { zc = tile % a.nzc; col = tile / a.nzc; }
+  else { const int t = tile - a.nA; zc = t % a.nzc; col = a.n64 * a.nty64 + t / a.nzc; }
 }
 
 // whole-wave lane shifts by DPP (VALU, no LDS round trip): lane l receives the value of lane l-1 (up) / l+1 (down); the lanes at the
@@ -76,6 +87,18 @@ __device__ const signed char kRows64[16] = {2, 4, 6, 8, 3, 5, 7, 9, 10, 11, 12, 
 __device__ const signed char kRows32a[16] = {2, 6, 10, 14, 3, 7, 11, 15, 18, 22, 26, 27, 19, 23, 0, 1};
 __device__ const signed char kRows32b[16] = {4, 8, 12, 16, 5, 9, 13, 17, 20, 24, 28, 29, 21, 25, 30, 31};
 
+// hardware-bounds-checked buffer access (raw buffer, stride 0): a lane whose byte offset lies outside the buffer loads 0 / stores nothing, so
+// the tile halo, the domain edge and the Dirichlet-mask conditions become OFFSETS instead of branches and the plane body stays one basic block
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;            // beyond any buffer this kernel accepts (kron_apply checks the size)
+__device__ inline void bload3(__amdgpu_buffer_rsrc_t r, unsigned off, double (&v)[3]) {
+  const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); const v2u u = __builtin_amdgcn_raw_buffer_load_b64(r, off + 16u, 0, 0);
+  v[0] = __hiloint2double(t.y, t.x); v[1] = __hiloint2double(t.w, t.z); v[2] = __hiloint2double(u.y, u.x);
+}
+__device__ inline double bload1(__amdgpu_buffer_rsrc_t r, unsigned off) { const v2u u = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); return __hiloint2double(u.y, u.x); }
+__device__ inline void bstore1(__amdgpu_buffer_rsrc_t r, unsigned off, double v) { v2u u; u.x = __double2loint(v); u.y = __double2hiint(v); __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0); }
+
 template <int TXN, bool CHEB>
 __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__restrict__ x, double *__restrict__ y, double *L, const int X0, const int tyi, const int zc) {
   constexpr int RPW = 64 / TXN, TYR = 16 * RPW, VY = TYR - 4;   // rows per wave, rows per tile, valid rows
@@ -95,21 +118,35 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
   const bool out = vn && lx >= 2 && lx <= TXN - 3 && !halo_wave;
   const bool bnd_xy = i == 0 || i == NX - 1 || j == 0 || j == NY - 1;
 
+  const unsigned n_nodes = (unsigned)NX * (unsigned)NY * (unsigned)NZ, nxy = (unsigned)NX * (unsigned)NY;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, n_nodes * 24u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(CHEB ? a.cheb.znew : y), 0, n_nodes * 24u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)a.nodemask, 0, a.constrained ? n_nodes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.cheb.g, 0, CHEB ? n_nodes * 24u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.cheb.cls, 0, CHEB ? n_nodes : 0u, 0x00020000);
+  const unsigned nxy_off = vn ? (unsigned)(j * NX + i) : kOOB;          // node offset inside a plane (invalid lanes: out of every buffer)
+  const unsigned out_off = out ? (unsigned)(j * NX + i) : kOOB;
+
   // centre coefficients (the only place the domain boundary enters); pe switches the +-2 messages off for mid nodes
-  const double mLx = i > 0 ? 1.0 : 0.0, mRx = i < NX - 1 ? 1.0 : 0.0, mLy = j > 0 ? 1.0 : 0.0, mRy = j < NY - 1 ? 1.0 : 0.0;
+  const double mLx = i > 0 ? 1.0 : 0.0, mRx = i < NX - 1 ? 1.0 : 0.0;
   const double pe = even_i ? 1.0 : 0.0;
   const double cMx = even_i ? 4.0 * (mLx + mRx) : 16.0, cKx = even_i ? 7.0 * (mLx + mRx) : 16.0, cDx = even_i ? 3.0 * (mLx - mRx) : 0.0;
-  const double cMy = odd_row ? 16.0 : 4.0 * (mLy + mRy), cKy = odd_row ? 16.0 : 7.0 * (mLy + mRy), cDy = odd_row ? 0.0 : 3.0 * (mLy - mRy);
+  // vertex rows (mid rows: 16, 16, 0 as literals); selected from literals so that a wave holding ONE row (64-lane tile) keeps them in scalar registers
+  const bool inner_y = j > 0 && j < NY - 1;
+  const double cMyv = inner_y ? 8.0 : 4.0, cKyv = inner_y ? 14.0 : 7.0, cDyv = inner_y ? 0.0 : (j > 0 ? 3.0 : -3.0);
   const KronConsts &K = a.k;
 
   // loads are asynchronous: the node's constraint bits (bit c = dof (node,c) is a Dirichlet dof) travel with the values and are
-  // applied only when the plane enters the window, so no wait on the in-flight prefetch is ever forced early
+  // applied only when the plane enters the window, so no wait on the in-flight prefetch is ever forced early.  Planes outside the box,
+  // nodes outside the domain and nodes whose mask cannot be set are out-of-range offsets: they load zeros without a branch
+  const bool mask_all = a.mask_anywhere != 0;
   auto load_plane = [&](int p, double (&v)[3], unsigned &m) {
-    v[0] = v[1] = v[2] = 0.0; m = 0;
-    if (p < 0 || p >= NZ || !vn) return;
-    const int64_t node = ((int64_t)p * NY + j) * NX + i;
-    v[0] = x[node * 3]; v[1] = x[node * 3 + 1]; v[2] = x[node * 3 + 2];
-    if (a.constrained && (a.mask_anywhere || p == 0 || p == NZ - 1 || bnd_xy)) m = a.nodemask[node];
+    const bool pin = p >= 0 && p < NZ;                                   // wave-uniform
+    const unsigned node = (unsigned)p * nxy + nxy_off;
+    const unsigned off = (pin && vn) ? node * 24u : kOOB;
+    bload3(rx, off, v);
+    const bool mk = pin && vn && (mask_all || p == 0 || p == NZ - 1 || bnd_xy);
+    m = __builtin_amdgcn_raw_buffer_load_b8(rm, mk ? node : kOOB, 0, 0);
   };
   auto apply_mask = [&](double (&v)[3], unsigned m) {
 #pragma unroll
@@ -120,20 +157,6 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
   unsigned m0, m1;
   load_plane(k0 - 2, W0, m0); apply_mask(W0, m0); load_plane(k0 - 1, W1, m0); apply_mask(W1, m0); load_plane(k0, W2, m0); apply_mask(W2, m0);
   load_plane(k0 + 1, W3, m0); apply_mask(W3, m0); load_plane(k0 + 2, W4, m0); apply_mask(W4, m0);
-
-  // y-stage helpers: neighbours and the node's own value of field q come from the LDS buffer `Lb`
-  const double *Lb = L;
-  double s1, s2, d1, d2, own;   // v(-1)+v(+1), v(-2)+v(+2), v(-1)-v(+1), v(+2)-v(-2), v(0)
-  auto nb = [&](int q) {
-    const double *col = Lb + (q * TYR + r) * TXN + lx;
-    const double nm1 = col[-TXN], np1 = col[TXN];
-    own = col[0];
-    s1 = nm1 + np1; d1 = nm1 - np1;
-    if (!odd_row) { const double nm2 = col[-2 * TXN], np2 = col[2 * TXN]; s2 = nm2 + np2; d2 = np2 - nm2; }
-  };
-  auto sweepM = [&]() { double s = fma(2.0, s1, cMy * own); if (!odd_row) s -= s2; return s; };
-  auto sweepK = [&]() { double s = fma(-8.0, s1, cKy * own); if (!odd_row) s += s2; return s; };
-  auto sweepO = [&]() { double s = 4.0 * d1; if (!odd_row) s += d2; return s; };
 
   // one plane: z-stage in registers -> LDS (double buffered: ONE barrier per plane) -> y-stage -> x-stage -> store
   int buf = 0;
@@ -169,95 +192,133 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
 #ifndef PORO_DIAG_NO_BARRIER
     __syncthreads();
 #endif
-    Lb = Lw; buf ^= 1;
+    const double *Lb = Lw; buf ^= 1;
 
     const bool has_w = !oddz && (kk == 0 || kk == NZ - 1);   // workgroup-uniform: first / last plane of the box
-    // x-stage of one component, scatter form: the node's own term + messages to the nodes at +-1 and (vertex nodes only) +-2
-    auto xstage = [&](const double FK, const double FM, const double FO, const double FD) {
-      const double t1 = fma(-8.0, FK, 2.0 * FM);         // K / M part of the +-1 coupling (the same for vertex and mid sources)
-      const double t2 = pe * (FK - FM);                  // +-2 coupling exists only between vertex nodes
-      const double pO = pe * FO;
-      double sacc = fma(cKx, FK, fma(cMx, FM, cDx * FD));
-#ifndef PORO_DIAG_NO_SHUFFLE
-      sacc += wave_up1(fma(4.0, FO, t1)) + wave_dn1(fma(-4.0, FO, t1));               // from i-1 (its +1 message) and i+1 (its -1 message)
-      sacc += wave_up1(wave_up1(t2 - pO)) + wave_dn1(wave_dn1(t2 + pO));              // from i-2 and i+2
-#else
-      sacc += fma(4.0, FO, t1) + fma(-4.0, FO, t1) + (t2 - pO) + (t2 + pO);
-#endif
-      return sacc;
-    };
     const double (&xc)[3] = oddz ? W3 : W2;            // this plane's (masked) input values, for the fused x.y
-    const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
-    // CHEB: x is the iterate z_j of the polynomial preconditioner in root form; instead of A z_j the kernel stores z_{j+1} = z_j + omega_j D^-1 (g - A z_j)
-    // (omega_j = reciprocal of a root of the shifted Chebyshev polynomial; z_{j+1} goes to the other buffer of a ping-pong pair because neighbouring
-    // tiles still read z_j) and accumulates g . z_{j+1}.  One extra read stream (g) instead of the two of the three-term recurrence.  Dirichlet dofs have
-    // D^-1 = 0 and z = 0.
-    const double *ctab = nullptr;
-    if constexpr (CHEB) ctab = a.cheb.tab + (out ? 3u * a.cheb.cls[d0 / 3] : 0u);
-    auto emit = [&](int c, double v) {
-      if (!out) return;
-      if constexpr (CHEB) {
-        const double gi = a.cheb.g[d0 + c];
-        const double zn = fma(a.cheb.omega * ctab[c], gi - v, xc[c]);
-        a.cheb.znew[d0 + c] = zn; dot_acc = fma(gi, zn, dot_acc);
-      } else { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); }   // Dirichlet rows: see the header
-    };
+    // everything behind the barrier is specialised on the row parity of the wave (one wave-uniform branch per plane instead of one per field):
+    // mid rows have 3-point y-bands and no boundary diagonal, vertex rows 5-point bands
+    auto rest = [&](auto ODD) {
+      constexpr bool odd = decltype(ODD)::value;
+      // y-stage helpers: neighbours and the node's own value of field q come from the LDS buffer `Lb`
+      double s1, s2 = 0.0, d1, d2 = 0.0, own;   // v(-1)+v(+1), v(-2)+v(+2), v(-1)-v(+1), v(+2)-v(-2), v(0)
+      auto nb = [&](int q) {
+        const double *col = Lb + (q * TYR + r) * TXN + lx;
+        const double nm1 = col[-TXN], np1 = col[TXN];
+        own = col[0];
+        s1 = nm1 + np1; d1 = nm1 - np1;
+        if constexpr (!odd) { const double nm2 = col[-2 * TXN], np2 = col[2 * TXN]; s2 = nm2 + np2; d2 = np2 - nm2; }
+      };
+      auto sweepM = [&]() { if constexpr (odd) return fma(2.0, s1, 16.0 * own); else return fma(2.0, s1, cMyv * own) - s2; };
+      auto sweepK = [&]() { if constexpr (odd) return fma(-8.0, s1, 16.0 * own); else return fma(-8.0, s1, cKyv * own) + s2; };
+      auto sweepO = [&]() { if constexpr (odd) return 4.0 * d1; else return fma(4.0, d1, d2); };
+      // c * D_y v + rest (D_y = boundary diagonal of C_y: vertex rows on the first / last row of the box only, never on mid rows)
+      auto fmaD = [&](double c, double rest_) { if constexpr (odd) return rest_; else return fma(c, cDyv * own, rest_); };
 
-    if (!has_w) {
+      // x-stage of one component, scatter form: the node's own term + messages to the nodes at +-1 and (vertex nodes only) +-2
+      auto xstage = [&](const double FK, const double FM, const double FO, const double FD) {
+        const double t1 = fma(-8.0, FK, 2.0 * FM);         // K / M part of the +-1 coupling (the same for vertex and mid sources)
+        const double t2 = pe * (FK - FM);                  // +-2 coupling exists only between vertex nodes
+        const double pO = pe * FO;
+        double sacc = fma(cKx, FK, fma(cMx, FM, cDx * FD));
+#ifndef PORO_DIAG_NO_SHUFFLE
+        // from i-1 (its +1 message) and i+1 (its -1 message); the messages from i-2 / i+2 ride along: shifted once on their own, then with the +-1 message
+        sacc += wave_up1(fma(4.0, FO, t1) + wave_up1(t2 - pO)) + wave_dn1(fma(-4.0, FO, t1) + wave_dn1(t2 + pO));
+#else
+        sacc += fma(4.0, FO, t1) + fma(-4.0, FO, t1) + (t2 - pO) + (t2 + pO);
+#endif
+        return sacc;
+      };
+      const unsigned d0b = ((unsigned)kk * nxy + out_off) * 24u;       // byte offset of the node's dofs; lanes without an output: out of range
+      const unsigned so = out ? d0b : kOOB;
+      // CHEB: x is the iterate z_j of the polynomial preconditioner in root form; instead of A z_j the kernel stores z_{j+1} = z_j + omega_j D^-1 (g - A z_j)
+      // (omega_j = reciprocal of a root of the shifted Chebyshev polynomial; z_{j+1} goes to the other buffer of a ping-pong pair because neighbouring
+      // tiles still read z_j) and accumulates g . z_{j+1}.  One extra read stream (g) instead of the two of the three-term recurrence.  Dirichlet dofs have
+      // D^-1 = 0 and z = 0.  Lanes without an output load g = 0 and store nothing.
+      const double *ctab = nullptr;
+      if constexpr (CHEB) ctab = a.cheb.tab + 3u * __builtin_amdgcn_raw_buffer_load_b8(rc, out ? (unsigned)kk * nxy + out_off : kOOB, 0, 0);
+      auto emit = [&](int c, double v) {
+        if constexpr (CHEB) {
+          const double gi = bload1(rg, so + 8u * c);
+          const double zn = fma(a.cheb.omega * ctab[c], gi - v, xc[c]);
+          bstore1(ry, so + 8u * c, zn); dot_acc = fma(gi, zn, dot_acc);
+        } else { bstore1(ry, so + 8u * c, v); dot_acc = fma(out ? xc[c] : 0.0, v, dot_acc); }   // Dirichlet rows: see the header
+      };
+
+      if (!has_w) {
+        if (halo_wave) return;
+        // field order chosen so that the inputs of component x, then y, then z complete early and their registers die.  The LDS reads of the NEXT
+        // field are issued before the arithmetic of the current one (two register sets, software-pipelined by hand: the compiler keeps the order)
+        struct Nb { double nm2, nm1, own, np1, np2; };
+        auto ld = [&](int q, Nb &n) {
+          const double *col = Lb + (q * TYR + r) * TXN + lx;
+          n.nm1 = col[-TXN]; n.np1 = col[TXN]; n.own = col[0];
+          if constexpr (!odd) { n.nm2 = col[-2 * TXN]; n.np2 = col[2 * TXN]; }
+        };
+        auto use = [&](const Nb &n) { own = n.own; s1 = n.nm1 + n.np1; d1 = n.nm1 - n.np1; if constexpr (!odd) { s2 = n.nm2 + n.np2; d2 = n.np2 - n.nm2; } };
+        Nb A, B;
+        double XK0, XM0, XO0, XD0, XK1, XM1, XO1, XD1;
+        ld(0, A); ld(3, B);
+        { use(A); const double My = sweepM(), Ky = sweepK(), Oy = sweepO();                  // mz_x
+          XK0 = K.xk_l2g * My; XM0 = K.m_gKyMz * Ky; XO1 = fmaD(K.cc_mz[2], K.cc_mz[0] * Oy); XD1 = fmaD(K.cc_mz[3], K.cc_mz[1] * Oy); }
+        ld(1, A);
+        { use(B); XM0 = fma(K.m_gMyKz, sweepM(), XM0); }                                     // kz_x
+        ld(8, B);
+        { use(A); const double My = sweepM(), Ky = sweepK(), Oy = sweepO();                  // mz_y
+          XK1 = K.xk_g * My; XM1 = K.m_lKyMz * Ky; XO0 = fmaD(K.cc_mz[1], K.cc_mz[0] * Oy); XD0 = fmaD(K.cc_mz[3], K.cc_mz[2] * Oy); }
+        ld(4, A);
+        { use(B); const double My = sweepM(), Oy = sweepO();                                 // oz_z
+          XO0 = fma(K.cc_oz[0], My, XO0); XD0 = fma(K.cc_oz[2], My, XD0); XM1 = fma(K.cc_mx[0], Oy, fmaD(K.cc_mx[2], XM1)); }
+        ld(2, B);
+        emit(0, xstage(XK0, XM0, XO0, XD0));
+        { use(A); XM1 = fma(K.m_gMyKz, sweepM(), XM1); }                                     // kz_y
+        ld(5, A);
+        emit(1, xstage(XK1, XM1, XO1, XD1));
+        double XK2, XM2, XO2, XD2;
+        { use(B); const double My = sweepM(), Ky = sweepK(); XK2 = K.xk_g * My; XM2 = K.m_gKyMz * Ky; }   // mz_z
+        ld(6, B);
+        { use(A); XM2 = fma(K.m_lMyKz, sweepM(), XM2); }                                     // kz_z
+        ld(7, A);
+        { use(B); const double My = sweepM(); XO2 = K.cc_oz[0] * My; XD2 = K.cc_oz[1] * My; } // oz_x
+        { use(A); const double Oy = sweepO(); XM2 = fma(K.cc_mx[0], Oy, fmaD(K.cc_mx[1], XM2)); }   // oz_y
+        emit(2, xstage(XK2, XM2, XO2, XD2));
+        return;
+      }
+
+      // first / last plane of the box (two planes per box): additionally the boundary diagonal D_z of C_z, wz = cD u, which goes
+      // through slots 0..2 of the same buffer in a second round
+      double XK[3], XM[3], XO[3], XD[3];
+      const double cD = 3.0 * ((kk > 0 ? 1.0 : 0.0) - (kk < NZ - 1 ? 1.0 : 0.0));
+      if (!halo_wave) {
+        { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO();                   // mz_x
+          XK[0] = K.xk_l2g * My; XM[0] = K.m_gKyMz * Ky; XO[1] = fmaD(K.cc_mz[2], K.cc_mz[0] * Oy); XD[1] = fmaD(K.cc_mz[3], K.cc_mz[1] * Oy); }
+        { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO();                   // mz_y
+          XK[1] = K.xk_g * My; XM[1] = K.m_lKyMz * Ky; XO[0] = fmaD(K.cc_mz[1], K.cc_mz[0] * Oy); XD[0] = fmaD(K.cc_mz[3], K.cc_mz[2] * Oy); }
+        { nb(2); const double My = sweepM(), Ky = sweepK(); XK[2] = K.xk_g * My; XM[2] = K.m_gKyMz * Ky; }   // mz_z
+        { nb(3); XM[0] = fma(K.m_gMyKz, sweepM(), XM[0]); }                                    // kz_x
+        { nb(4); XM[1] = fma(K.m_gMyKz, sweepM(), XM[1]); }                                    // kz_y
+        { nb(5); XM[2] = fma(K.m_lMyKz, sweepM(), XM[2]); }                                    // kz_z
+        { nb(6); const double My = sweepM(); XO[2] = K.cc_oz[0] * My; XD[2] = K.cc_oz[1] * My; }   // oz_x
+        { nb(7); const double Oy = sweepO(); XM[2] = fma(K.cc_mx[0], Oy, fmaD(K.cc_mx[1], XM[2])); }   // oz_y
+        { nb(8); const double My = sweepM(), Oy = sweepO();                                    // oz_z
+          XO[0] = fma(K.cc_oz[0], My, XO[0]); XD[0] = fma(K.cc_oz[2], My, XD[0]); XM[1] = fma(K.cc_mx[0], Oy, fmaD(K.cc_mx[2], XM[1])); }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Lw[(c * TYR + r) * TXN + lx] = cD * xc[c];
+      __syncthreads();
+      if (!halo_wave) {
+        { nb(0); const double My = sweepM(); XO[2] = fma(K.cc_oz[2], My, XO[2]); XD[2] = fma(K.cc_oz[3], My, XD[2]); }            // wz_x
+        { nb(1); const double Oy = sweepO(); XM[2] = fma(K.cc_mx[2], Oy, fmaD(K.cc_mx[3], XM[2])); }                              // wz_y
+        { nb(2); const double My = sweepM(), Oy = sweepO();                                                                       // wz_z
+          XO[0] = fma(K.cc_oz[1], My, XO[0]); XD[0] = fma(K.cc_oz[3], My, XD[0]); XM[1] = fma(K.cc_mx[1], Oy, fmaD(K.cc_mx[3], XM[1])); }
+      }
+      __syncthreads();   // slots 0..2 must not be overwritten by a fast wave's plane kk+2 before everybody has read wz (same buffer)
       if (halo_wave) return;
-      // field order chosen so that the inputs of component x, then y, then z complete early and their registers die
-      double XK0, XM0, XO0, XD0, XK1, XM1, XO1, XD1;
-      { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_x
-        XK0 = K.xk_l2g * My; XM0 = K.m_gKyMz * Ky; XO1 = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD1 = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
-      { nb(3); XM0 = fma(K.m_gMyKz, sweepM(), XM0); }                                      // kz_x
-      { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_y
-        XK1 = K.xk_g * My; XM1 = K.m_lKyMz * Ky; XO0 = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD0 = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
-      { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                  // oz_z
-        XO0 = fma(K.cc_oz[0], My, XO0); XD0 = fma(K.cc_oz[2], My, XD0); XM1 = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM1)); }
-      emit(0, xstage(XK0, XM0, XO0, XD0));
-      { nb(4); XM1 = fma(K.m_gMyKz, sweepM(), XM1); }                                      // kz_y
-      emit(1, xstage(XK1, XM1, XO1, XD1));
-      double XK2, XM2, XO2, XD2;
-      { nb(2); const double My = sweepM(), Ky = sweepK(); XK2 = K.xk_g * My; XM2 = K.m_gKyMz * Ky; }   // mz_z
-      { nb(5); XM2 = fma(K.m_lMyKz, sweepM(), XM2); }                                      // kz_z
-      { nb(6); const double My = sweepM(); XO2 = K.cc_oz[0] * My; XD2 = K.cc_oz[1] * My; } // oz_x
-      { nb(7); const double Oy = sweepO(), Dy = cDy * own; XM2 = fma(K.cc_mx[0], Oy, fma(K.cc_mx[1], Dy, XM2)); }   // oz_y
-      emit(2, xstage(XK2, XM2, XO2, XD2));
-      return;
-    }
-
-    // first / last plane of the box (two planes per box): additionally the boundary diagonal D_z of C_z, wz = cD u, which goes
-    // through slots 0..2 of the same buffer in a second round
-    double XK[3], XM[3], XO[3], XD[3];
-    const double cD = 3.0 * ((kk > 0 ? 1.0 : 0.0) - (kk < NZ - 1 ? 1.0 : 0.0));
-    if (!halo_wave) {
-      { nb(0); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_x
-        XK[0] = K.xk_l2g * My; XM[0] = K.m_gKyMz * Ky; XO[1] = fma(K.cc_mz[2], Dy, K.cc_mz[0] * Oy); XD[1] = fma(K.cc_mz[3], Dy, K.cc_mz[1] * Oy); }
-      { nb(1); const double My = sweepM(), Ky = sweepK(), Oy = sweepO(), Dy = cDy * own;   // mz_y
-        XK[1] = K.xk_g * My; XM[1] = K.m_lKyMz * Ky; XO[0] = fma(K.cc_mz[1], Dy, K.cc_mz[0] * Oy); XD[0] = fma(K.cc_mz[3], Dy, K.cc_mz[2] * Oy); }
-      { nb(2); const double My = sweepM(), Ky = sweepK(); XK[2] = K.xk_g * My; XM[2] = K.m_gKyMz * Ky; }   // mz_z
-      { nb(3); XM[0] = fma(K.m_gMyKz, sweepM(), XM[0]); }                                    // kz_x
-      { nb(4); XM[1] = fma(K.m_gMyKz, sweepM(), XM[1]); }                                    // kz_y
-      { nb(5); XM[2] = fma(K.m_lMyKz, sweepM(), XM[2]); }                                    // kz_z
-      { nb(6); const double My = sweepM(); XO[2] = K.cc_oz[0] * My; XD[2] = K.cc_oz[1] * My; }   // oz_x
-      { nb(7); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[1], Dy, XM[2])); }   // oz_y
-      { nb(8); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                    // oz_z
-        XO[0] = fma(K.cc_oz[0], My, XO[0]); XD[0] = fma(K.cc_oz[2], My, XD[0]); XM[1] = fma(K.cc_mx[0], Oy, fma(K.cc_mx[2], Dy, XM[1])); }
-    }
-    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Lw[(c * TYR + r) * TXN + lx] = cD * xc[c];
-    __syncthreads();
-    if (!halo_wave) {
-      { nb(0); const double My = sweepM(); XO[2] = fma(K.cc_oz[2], My, XO[2]); XD[2] = fma(K.cc_oz[3], My, XD[2]); }            // wz_x
-      { nb(1); const double Oy = sweepO(), Dy = cDy * own; XM[2] = fma(K.cc_mx[2], Oy, fma(K.cc_mx[3], Dy, XM[2])); }           // wz_y
-      { nb(2); const double My = sweepM(), Oy = sweepO(), Dy = cDy * own;                                                       // wz_z
-        XO[0] = fma(K.cc_oz[1], My, XO[0]); XD[0] = fma(K.cc_oz[3], My, XD[0]); XM[1] = fma(K.cc_mx[1], Oy, fma(K.cc_mx[3], Dy, XM[1])); }
-    }
-    __syncthreads();   // slots 0..2 must not be overwritten by a fast wave's plane kk+2 before everybody has read wz (same buffer)
-    if (halo_wave) return;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) emit(c, xstage(XK[c], XM[c], XO[c], XD[c]));
+      for (int c = 0; c < 3; ++c) emit(c, xstage(XK[c], XM[c], XO[c], XD[c]));
+    };
+    if (odd_row) rest(std::true_type{}); else rest(std::false_type{});
   };
 
   for (int k = k0; k < k1; k += 2) {
@@ -282,9 +343,9 @@ __global__ void __launch_bounds__(1024)
 k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];                            // [2 buffers][9 fields][1024 nodes of the tile plane]
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;  // uniform over the grid: written by the previous launches only
-  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);  // workgroup-uniform: either tile shape, never both
-  if (tile < a.nA) kron_tile<64, false>(a, x, y, L, 60 * (tile / (a.nzc * a.nty64)) - 2, (tile / a.nzc) % a.nty64, tile % a.nzc);
-  else { const int t = tile - a.nA; kron_tile<32, false>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+  int col, zc; tile_of(a, col, zc);                        // workgroup-uniform: either tile shape, never both
+  if (col < a.n64 * a.nty64) kron_tile<64, false>(a, x, y, L, 60 * (col / a.nty64) - 2, col % a.nty64, zc);
+  else kron_tile<32, false>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
 }
 // the same sweep with the Chebyshev (root form) update fused into the stores (polynomial preconditioner of the displacement CG: no vector kernels and no
 // reductions between the operator applications of one preconditioner call)
@@ -292,9 +353,9 @@ __global__ void __launch_bounds__(1024)
 k_kron3_q2_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
-  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
-  if (tile < a.nA) kron_tile<64, true>(a, x, y, L, 60 * (tile / (a.nzc * a.nty64)) - 2, (tile / a.nzc) % a.nty64, tile % a.nzc);
-  else { const int t = tile - a.nA; kron_tile<32, true>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+  int col, zc; tile_of(a, col, zc);                        // workgroup-uniform: either tile shape, never both
+  if (col < a.n64 * a.nty64) kron_tile<64, true>(a, x, y, L, 60 * (col / a.nty64) - 2, col % a.nty64, zc);
+  else kron_tile<32, true>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
 }
 
 
@@ -457,17 +518,17 @@ __global__ void __launch_bounds__(1024)
 k_kron3_q1(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
-  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
-  if (tile < a.nA) kron_tile_q1<64, false>(a, x, y, L, 62 * (tile / (a.nzc * a.nty64)) - 1, (tile / a.nzc) % a.nty64, tile % a.nzc);
-  else { const int t = tile - a.nA; kron_tile_q1<32, false>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+  int col, zc; tile_of(a, col, zc);
+  if (col < a.n64 * a.nty64) kron_tile_q1<64, false>(a, x, y, L, 62 * (col / a.nty64) - 1, col % a.nty64, zc);
+  else kron_tile_q1<32, false>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
 }
 __global__ void __launch_bounds__(1024)
 k_kron3_q1_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
-  const int tile = (int)xcd_remap(blockIdx.x, a.nblocks);
-  if (tile < a.nA) kron_tile_q1<64, true>(a, x, y, L, 62 * (tile / (a.nzc * a.nty64)) - 1, (tile / a.nzc) % a.nty64, tile % a.nzc);
-  else { const int t = tile - a.nA; kron_tile_q1<32, true>(a, x, y, L, a.x0_32, t / a.nzc, t % a.nzc); }
+  int col, zc; tile_of(a, col, zc);
+  if (col < a.n64 * a.nty64) kron_tile_q1<64, true>(a, x, y, L, 62 * (col / a.nty64) - 1, col % a.nty64, zc);
+  else kron_tile_q1<32, true>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
 }
 
 // ---- 2D (Q2 and Q1): A_xx = (l+2G) Kx (x) My + G Mx (x) Ky,  A_yy = G Kx (x) My + (l+2G) Mx (x) Ky,
@@ -617,6 +678,7 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
     else hipExtLaunchKernelGGL(k_kron2<1>, dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
     return (int)grid;
   }
+  if ((int64_t)a.nn[0] * a.nn[1] * a.nn[2] * 24 >= (int64_t)1 << 31) throw Error("structured operator: more than 2^31 bytes per displacement vector (32-bit buffer offsets)");
   // tile shapes: (64 lanes x 16 rows) and (32 x 32); valid outputs 60 x 12 / 28 x 28 for Q2 (halo 2), 62 x 14 / 30 x 30 for Q1 (halo 1)
   const int vx64 = ku == 2 ? 60 : 62, vx32 = ku == 2 ? 28 : 30, vy64 = ku == 2 ? 12 : 14, vy32 = ku == 2 ? 28 : 30, halo = ku == 2 ? 2 : 1;
   // x-extent = full 64-lane tiles + (when what is left fits) one 32-lane tile column
@@ -633,7 +695,8 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   const int upc = 8 / a.zunit;                                   // units in a chunk of 8 planes
   int nzc = n_cus / cols; if (nzc > (units + upc - 1) / upc) nzc = (units + upc - 1) / upc; if (nzc < 1) nzc = 1;
   a.nzc = nzc; a.zq = units / nzc; a.zr = units % nzc;
-  a.nA = a.n64 * a.nty64 * a.nzc; a.nblocks = a.nA + a.has32 * a.nty32 * a.nzc;
+  a.nA = a.n64 * a.nty64 * a.nzc; a.nblocks = a.nA + a.has32 * a.nty32 * a.nzc; a.cols = cols;
+  { static const int zm = std::getenv("PORO_KRON_COLMAJOR") ? 0 : 1; a.zmajor = zm; }
   const double lam = m.lam, G = m.G, l2g = lam + 2 * G, c[4] = {-(lam + G), lam - G, G - lam, lam + G};
   const double mdiv = ku == 2 ? 30.0 : 6.0, kmul = ku == 2 ? 1.0 / 3.0 : 1.0, sC = ku == 2 ? 1.0 / 6 : 0.5;   // scales of the integer 1D matrices
   const double sM[3] = {m.box.h[0] / mdiv, m.box.h[1] / mdiv, m.box.h[2] / mdiv}, sK[3] = {kmul / m.box.h[0], kmul / m.box.h[1], kmul / m.box.h[2]};

@@ -47,3 +47,11 @@ def node_coords_box(dim, n, degree, size=10.0):
 def csr_to_scipy(rp, col, val):
     import scipy.sparse as sp
     return sp.csr_matrix((val, col, rp), shape=(len(rp) - 1, len(rp) - 1))
+
+
+def global_problem(mesh, deg):
+    """global (unpartitioned) problem of the general-partition tests: mesh = "gmsh" (the bundled domain.msh) | "box:nx,ny[,nz]" """
+    if mesh == "gmsh":
+        return pk.Problem.gmsh(DOMAIN_MSH, deg, material(), BC_2D)
+    n = [int(v) for v in mesh.split(":")[1].split(",")]
+    return box_problem(len(n), n, deg)

@@ -16,14 +16,7 @@ import torch.distributed as dist  # noqa: E402
 
 import poroelasticity_dealii_amd as pk  # noqa: E402
 import oracle_py  # noqa: E402
-from common import REF, BC_2D, DOMAIN_MSH, box_problem, material  # noqa: E402
-
-
-def global_problem(mesh, deg):
-    if mesh == "gmsh":
-        return pk.Problem.gmsh(DOMAIN_MSH, deg, material(), BC_2D)
-    n = [int(v) for v in mesh.split(":")[1].split(",")]
-    return box_problem(len(n), n, deg)
+from common import REF, global_problem  # noqa: E402
 
 
 def main():

@@ -10,7 +10,7 @@ import pytest
 
 import poroelasticity_dealii_amd as pk
 import oracle_py
-from common import REF
+from common import REF, global_problem
 from test_multirank_cpu import HERE, free_port
 
 
@@ -36,7 +36,6 @@ def assemble_global(R, key, l2g, n):
 
 
 def check_against_single_rank(R, mesh, deg, tol_u=1e-9):
-    from mr_general_worker import global_problem
     P = global_problem(mesh, deg)
     O = oracle_py.Oracle(P, hoisted=True)
     try:
@@ -67,7 +66,6 @@ def test_general_partition_time_step_equals_single_rank(tmp_path, world, mesh, d
 
 def test_partition_bookkeeping():
     """pieces of the Gmsh mesh: cells are split exactly, interface lists are symmetric and in the same (global) order on both sides, owned dofs come first"""
-    from mr_general_worker import global_problem
     PG = global_problem("gmsh", 2)
     world = 3
     pieces = [PG.partition(r, world) for r in range(world)]
