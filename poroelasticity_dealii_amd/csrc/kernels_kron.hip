@@ -149,6 +149,7 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
     m = __builtin_amdgcn_raw_buffer_load_b8(rm, mk ? node : kOOB, 0, 0);
   };
   auto apply_mask = [&](double (&v)[3], unsigned m) {
+    if (__builtin_amdgcn_ballot_w64(m != 0) == 0) return;      // no Dirichlet dof in this wave's row of the plane (every interior tile): skip the selects
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (m & (1u << c)) v[c] = 0.0;
   };
@@ -242,7 +243,7 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
           const double gi = bload1(rg, so + 8u * c);
           const double zn = fma(a.cheb.omega * ctab[c], gi - v, xc[c]);
           bstore1(ry, so + 8u * c, zn); dot_acc = fma(gi, zn, dot_acc);
-        } else { bstore1(ry, so + 8u * c, v); dot_acc = fma(out ? xc[c] : 0.0, v, dot_acc); }   // Dirichlet rows: see the header
+        } else { bstore1(ry, so + 8u * c, v); dot_acc = fma(xc[c], v, dot_acc); }   // Dirichlet rows: see the header; lanes without an output are dropped from the sum at the end
       };
 
       if (!has_w) {
@@ -330,6 +331,7 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
     apply_mask(W3, m0); apply_mask(W4, m1);
   }
   if (a.dot_partials) {   // deterministic workgroup reduction of x.y (fixed shuffle tree, waves summed in index order)
+    if (!out) dot_acc = 0.0;                                   // halo lanes / rows accumulated finite garbage
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_xor(dot_acc, off, 64);
     __syncthreads();
