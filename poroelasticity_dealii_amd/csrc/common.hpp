@@ -42,6 +42,9 @@ struct PcgScalars {
   int32_t it, done, converged, max_iter, finishing, pad_;
 };
 
+// device-side state of the single-reduction PCG (partitioned runs)
+struct Cg1State { double gamma_old, alpha_old, alpha, beta, tol, res0, res; int32_t it, done, converged, pad_; };
+
 // INVERSE Jacobi diagonal handed to the PCG kernels (they multiply): the full vector of reciprocals, or (uniform boxes) a class byte
 // per node + table[class][component] of reciprocals
 // reciprocal Jacobi diagonal; a ZERO entry marks an inert (Dirichlet) dof that PCG leaves alone; `inert` is the same set as a byte mask
@@ -166,6 +169,7 @@ struct poro_ctx {
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
+  poro::DevBuf<poro::Cg1State> cg1_state; poro::DevBuf<double> cg1_z[2], cg1_w[2];   // single-reduction PCG of partitioned runs ([0]: displacement-sized, [1]: pressure-sized)
   bool matrix_built = false;
   int interleaved_u = 0;
   int pcg_hint_fdm_u[2] = {0, 0}, pcg_hint_cheb_u[2] = {0, 0}; int64_t cheb_applies = 0;
@@ -220,6 +224,9 @@ void la_mask_zero(hipStream_t s, double *x, const uint8_t *mask, int64_t n);
 void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials);
 void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVec &diag, int prec, int64_t n, int64_t n_owned, double *partials /*2 sets: gg, gz*/);
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red);
+void cg1_dots(hipStream_t s, const double *g, const double *z, const double *w, const double *b /*nullable: adds b.b*/, int64_t n_owned, double *partials /*4 sets*/);
+void cg1_scalars(hipStream_t s, Cg1State *st, const double *red, int first, double abs_tol, double rel_tol, int max_iter, int stop_rule);
+void cg1_update(hipStream_t s, const Cg1State *st, double *d, double *sv, double *x, double *g, const double *z, const double *w, const uint8_t *inert, int64_t n);
 void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red /*bb, gg, gz*/, double abs_tol, double rel_tol, int max_iter, int stop_rule);
 // single-rank fast path: the consumers reduce the block partials themselves (no scalar kernels, no host round trip);
 // parity = iteration index & 1 selects the g.z slot read / written

@@ -304,6 +304,58 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
   return fused;
 }
 
+// ---- single-reduction PCG for partitioned runs (Chronopoulos & Gear) ------------------------------------------------------------------
+// Same Krylov space, same stopping test and same iteration count as SolverCG's recurrence in exact arithmetic, rearranged so that an iteration
+// costs ONE all-reduce: z = P^-1 g, w = A z, then {g.z, w.z, g.g} in one reduction, then d = -z + beta d, s = -w + beta s (= A d), x += alpha d,
+// g += alpha s.  Per iteration: 1 operator application (1 grouped neighbour exchange) + the exchanges inside P^-1 + 1 all-reduce of 4 doubles.
+// The price is two more vector passes than pcg(), which is why single-rank runs keep the three-kernel recurrence.
+int pcg_single_reduction(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
+                         const DiagVec &diag, double *g, double *d, double *sv, const poro_solver_opts *opts, poro_solve_info *info,
+                         const std::function<bool(const double *, double *, double *)> *precond, int *its_hint) {
+  hipStream_t s = c->stream;
+  const int which = n == c->n_u ? 0 : 1;
+  if (c->cg1_w[which].n < (size_t)n) { c->cg1_w[which].alloc(n); c->cg1_z[which].alloc(n); }
+  if (!c->cg1_state.p) c->cg1_state.alloc(1);
+  double *w = c->cg1_w[which].p, *z = (precond && diag.z) ? const_cast<double *>(diag.z) : c->cg1_z[which].p;
+  if (precond && !diag.z) throw Error("pcg: explicit preconditioner without a z vector");
+  const int64_t n_own = owned(c, n, plane);
+  const bool jacobi = opts->preconditioner == PORO_PREC_JACOBI;
+  Cg1State *st = c->cg1_state.p; double *part = c->partials.p, *red = c->red.p;
+  EventPair ev(c); PORO_HIP(hipEventRecord(ev.e0, s));
+  apply(x, w, nullptr);
+  pcg_init_residual(s, g, w, b, diag.inert, n);        // g = A x - b, zero on the inert dofs
+  la_fill(s, d, 0.0, n); la_fill(s, sv, 0.0, n);
+  Cg1State hs{};
+  int expect = 0, enq = 0;
+  if (its_hint && its_hint[0] > 0) { expect = its_hint[1] > 0 ? 2 * its_hint[0] - its_hint[1] : its_hint[0]; expect = std::max(expect, its_hint[0] / 2); }
+  auto next_batch = [&](int done_its) { const int left = expect - 4 - done_its; return left >= 4 ? std::min(32, left) : 2; };
+  int batch = expect > 0 ? next_batch(0) : 1;
+  while (true) {
+    for (int k = 0; k < batch; ++k) {
+      if (precond) (void)(*precond)(g, z, nullptr);
+      else if (jacobi) la_cheb_first(s, z, g, diag, 1.0, n);        // z = D^-1 g (zero on the inert dofs)
+      else la_copy(s, z, g, n);
+      apply(z, w, nullptr);
+      cg1_dots(s, g, z, w, enq == 0 ? b : nullptr, n_own, part);
+      pcg_scalars_sum(s, part, 4, red);
+      allreduce_sum(c, red, 4);
+      cg1_scalars(s, st, red, enq == 0 ? 1 : 0, opts->abs_tol, opts->rel_tol, opts->max_iter, opts->stop_rule);
+      cg1_update(s, st, d, sv, x, g, z, w, diag.inert, n);
+      ++enq;
+    }
+    PORO_HIP(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+    if (hs.done) break;
+    // (the preconditioner and operator launches of an iteration are not gated by the device-side `done` flag: without a hint poll at least every 8 iterations)
+    if (expect > 0) batch = next_batch(enq); else if (batch < 8) batch *= 2;
+  }
+  if (its_hint) { its_hint[1] = its_hint[0]; its_hint[0] = hs.it; }
+  PORO_HIP(hipEventRecord(ev.e1, s)); PORO_HIP(hipEventSynchronize(ev.e1));
+  float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  if (info) { info->iterations = hs.it; info->converged = hs.converged; info->initial_residual = hs.res0; info->final_residual = hs.res; info->seconds = ms * 1e-3;
+              info->operator_applications = hs.it + 2; }   // initial residual + one per iteration + the one that found the converged residual
+  return hs.converged ? 0 : 1;
+}
+
 // ---- PCG with device-side control: SolverCG<>::solve restated, Jacobi instead of SSOR ---------------
 // apply(x, y, dot_partials) as apply_A_u.  The vector kernels compute alpha / beta / the stopping test in their prologues: from the
 // block partials (single rank, 3 launches per iteration incl. the operator) or from the all-reduced scalars (partitioned).
@@ -313,6 +365,8 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
 int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
         const DiagVec &diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info,
         const std::function<bool(const double *, double *, double *)> *precond = nullptr, int *its_hint = nullptr) {
+  static const bool two_reductions = std::getenv("PORO_TWO_REDUCTION_CG") != nullptr;    // A/B hook: the three-kernel recurrence on partitioned runs too
+  if (c->comm.multi() && !two_reductions) return pcg_single_reduction(c, apply, n, plane, x, b, diag, g, d, h, opts, info, precond, its_hint);
   hipStream_t s = c->stream;
   const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
   double *zbuf = const_cast<double *>(diag.z);

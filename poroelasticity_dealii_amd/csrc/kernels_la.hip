@@ -555,6 +555,56 @@ void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVe
 void pcg_dot_dh(hipStream_t s, const PcgScalars *sc, const double *d, const double *h, int64_t n_owned, double *partials) {
   hipLaunchKernelGGL(k_pcg_dot_dh, reduce_grid(n_owned), kBlock, 0, s, sc, d, h, n_owned, partials);
 }
+// ---- single-reduction PCG (Chronopoulos & Gear): partitioned runs pay ONE all-reduce per iteration ------------------------------------
+// With z = P^-1 g and w = A z the three dots g.z, w.z, g.g of an iteration are independent of each other, so they travel in one reduction;
+// A d follows from the recurrence s = -w + beta s instead of a second operator application.
+__global__ void k_cg1_dots(const double *__restrict__ g, const double *__restrict__ z, const double *__restrict__ w, const double *__restrict__ b, int64_t n_owned, double *partials) {
+  __shared__ double sh[4];
+  double gz = 0, wz = 0, gg = 0, bb = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_owned; i += (int64_t)gridDim.x * kBlock) {
+    const double gi = g[i], zi = z[i];
+    gz += gi * zi; wz += w[i] * zi; gg += gi * gi;
+    if (b) { const double bi = b[i]; bb += bi * bi; }
+  }
+  gz = block_sum(gz, sh); store_partial(partials, gz);
+  wz = block_sum(wz, sh); store_partial(partials + kMaxPartials, wz);
+  gg = block_sum(gg, sh); store_partial(partials + 2 * kMaxPartials, gg);
+  bb = block_sum(bb, sh); store_partial(partials + 3 * kMaxPartials, bb);
+}
+// red = {g.z, w.z, g.g, b.b} after the all-reduce.  SolverCG's control flow: stop when ||g|| <= tol (checked before the update that would follow), give up at max_iter
+__global__ void k_cg1_scalars(Cg1State *st, const double *red, int first, double abs_tol, double rel_tol, int max_iter, int stop_rule) {
+  const double gamma = red[0], delta = red[1], gg = red[2];
+  if (first) {
+    st->tol = fmax(abs_tol, rel_tol * sqrt(stop_rule == PORO_STOP_REDUCTION ? gg : red[3]));
+    st->res0 = sqrt(gg); st->it = 0; st->done = 0; st->converged = 0; st->gamma_old = 0; st->alpha_old = 0;
+  }
+  if (st->done) return;
+  st->res = sqrt(gg);
+  if (st->res <= st->tol) { st->converged = 1; st->done = 1; return; }
+  if (st->it >= max_iter) { st->done = 1; return; }
+  const double beta = first ? 0.0 : gamma / st->gamma_old;
+  const double alpha = first ? gamma / delta : gamma / (delta - beta * gamma / st->alpha_old);
+  st->alpha = alpha; st->beta = beta; st->gamma_old = gamma; st->alpha_old = alpha; st->it += 1;
+}
+// d = -z + beta d, s = -w + beta s (= A d), x += alpha d, g += alpha s; inert (Dirichlet) dofs keep d = s = 0 whatever the operator left in w there
+__global__ void k_cg1_update(const Cg1State *st, double *d, double *sv, double *x, double *g, const double *__restrict__ z, const double *__restrict__ w, const uint8_t *inert, int64_t n) {
+  if (st->done) return;
+  const double alpha = st->alpha, beta = st->beta;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    if (inert && inert[i]) continue;
+    const double di = fma(beta, d[i], -z[i]), si = fma(beta, sv[i], -w[i]);
+    d[i] = di; sv[i] = si; x[i] = fma(alpha, di, x[i]); g[i] = fma(alpha, si, g[i]);
+  }
+}
+void cg1_dots(hipStream_t s, const double *g, const double *z, const double *w, const double *b, int64_t n_owned, double *partials) {
+  hipLaunchKernelGGL(k_cg1_dots, reduce_grid(n_owned), kBlock, 0, s, g, z, w, b, n_owned, partials);
+}
+void cg1_scalars(hipStream_t s, Cg1State *st, const double *red, int first, double abs_tol, double rel_tol, int max_iter, int stop_rule) {
+  hipLaunchKernelGGL(k_cg1_scalars, 1, 1, 0, s, st, red, first, abs_tol, rel_tol, max_iter, stop_rule);
+}
+void cg1_update(hipStream_t s, const Cg1State *st, double *d, double *sv, double *x, double *g, const double *z, const double *w, const uint8_t *inert, int64_t n) {
+  hipLaunchKernelGGL(k_cg1_update, grid_for(n), kBlock, 0, s, st, d, sv, x, g, z, w, inert, n);
+}
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red) {
   hipLaunchKernelGGL(k_scalars_sum, 1, kBlock, 0, s, (const PcgScalars *)nullptr, partials, n_sets, red);
 }
