@@ -384,14 +384,24 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
   const double cMx = 2.0 * (mLx + mRx), cKx = mLx + mRx, cDx = mLx - mRx, cMy = 2.0 * (mLy + mRy), cKy = mLy + mRy, cDy = mLy - mRy;
   const KronConsts &K = a.k;
 
+  // bounds-checked buffer access as in kron_tile: halo / out-of-domain / unmasked conditions are out-of-range offsets, not branches
+  const unsigned n_nodes = (unsigned)NX * (unsigned)NY * (unsigned)NZ, nxy = (unsigned)NX * (unsigned)NY;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, n_nodes * 24u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(CHEB ? a.cheb.znew : y), 0, n_nodes * 24u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)a.nodemask, 0, a.constrained ? n_nodes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.cheb.g, 0, CHEB ? n_nodes * 24u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.cheb.cls, 0, CHEB ? n_nodes : 0u, 0x00020000);
+  const unsigned nxy_off = vn ? (unsigned)(j * NX + i) : kOOB, out_off = out ? (unsigned)(j * NX + i) : kOOB;
+  const bool mask_all = a.mask_anywhere != 0;
   auto load_plane = [&](int p, double (&v)[3], unsigned &m) {
-    v[0] = v[1] = v[2] = 0.0; m = 0;
-    if (p < 0 || p >= NZ || !vn) return;
-    const int64_t node = ((int64_t)p * NY + j) * NX + i;
-    v[0] = x[node * 3]; v[1] = x[node * 3 + 1]; v[2] = x[node * 3 + 2];
-    if (a.constrained && (a.mask_anywhere || p == 0 || p == NZ - 1 || bnd_xy)) m = a.nodemask[node];
+    const bool pin = p >= 0 && p < NZ;
+    const unsigned node = (unsigned)p * nxy + nxy_off;
+    bload3(rx, (pin && vn) ? node * 24u : kOOB, v);
+    const bool mk = pin && vn && (mask_all || p == 0 || p == NZ - 1 || bnd_xy);
+    m = __builtin_amdgcn_raw_buffer_load_b8(rm, mk ? node : kOOB, 0, 0);
   };
   auto apply_mask = [&](double (&v)[3], unsigned m) {
+    if (__builtin_amdgcn_ballot_w64(m != 0) == 0) return;
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (m & (1u << c)) v[c] = 0.0;
   };
@@ -436,16 +446,15 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
       const double t1 = FM - FK;
       return fma(cKx, FK, fma(cMx, FM, cDx * FD)) + wave_up1(t1 + FO) + wave_dn1(t1 - FO);   // from i-1 and i+1
     };
-    const int64_t d0 = (((int64_t)kk * NY + j) * NX + i) * 3;
+    const unsigned so = out ? ((unsigned)kk * nxy + out_off) * 24u : kOOB;
     const double *ctab = nullptr;
-    if constexpr (CHEB) ctab = a.cheb.tab + (out ? 3u * a.cheb.cls[d0 / 3] : 0u);
+    if constexpr (CHEB) ctab = a.cheb.tab + 3u * __builtin_amdgcn_raw_buffer_load_b8(rc, out ? (unsigned)kk * nxy + out_off : kOOB, 0, 0);
     auto emit = [&](int c, double v) {
-      if (!out) return;
       if constexpr (CHEB) {      // see kron_tile
-        const double gi = a.cheb.g[d0 + c];
+        const double gi = bload1(rg, so + 8u * c);
         const double zn = fma(a.cheb.omega * ctab[c], gi - v, xc[c]);
-        a.cheb.znew[d0 + c] = zn; dot_acc = fma(gi, zn, dot_acc);
-      } else { y[d0 + c] = v; dot_acc = fma(xc[c], v, dot_acc); }
+        bstore1(ry, so + 8u * c, zn); dot_acc = fma(gi, zn, dot_acc);
+      } else { bstore1(ry, so + 8u * c, v); dot_acc = fma(xc[c], v, dot_acc); }
     };
 
     if (!has_w) {
@@ -507,6 +516,7 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
     apply_mask(W2, mp);
   }
   if (a.dot_partials) {
+    if (!out) dot_acc = 0.0;                                   // lanes without an output accumulated finite garbage
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_xor(dot_acc, off, 64);
     __syncthreads();
