@@ -133,7 +133,7 @@ def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist,
         n[dim - 1] = args.n * world; size[dim - 1] = 10.0 * world
     P = pk.Problem.box(dim, n, size, deg, material(), BC_3D[:2 * dim], (), rank, world)
     R = pk.Runner(P, device=local_rank, operator_mode=pk.OP_MATRIX_FREE, p_init=INPUT["p_init"], dt=INPUT["dt"], abs_u=1e-12, rel_u=args.rel_tol, max_it=args.max_iter,
-                  prec=pk.PREC_JACOBI if prec is None else prec, reduction=args.stop == "reduction", cheb_degree=args.cheb_degree)
+                  prec=pk.PREC_JACOBI if prec is None else prec, reduction=args.stop == "reduction", cheb_degree=args.cheb_degree, cheb_ratio=args.cheb_ratio)
     G = R.ctx
     if world > 1 and args.share_gpu:
         import numpy as np
@@ -221,6 +221,7 @@ def main():
                     help="preconditioner of the displacement CG in the headline run: chebyshev = Chebyshev polynomial around Jacobi, on 3D boxes fused into the operator kernel "
                          "(the other one and the block fast diagonalisation are measured as well and reported under time_to_solution)")
     ap.add_argument("--cheb-degree", type=int, default=6)
+    ap.add_argument("--cheb-ratio", type=int, default=0, help="lambda_max / lambda_min of the Chebyshev interval (0: the library default, a few times the mesh-dependent lambda_min)")
     ap.add_argument("--max-iter", type=int, default=50000)
     ap.add_argument("--cpu-n", type=int, default=9, help="cells per direction of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -109,3 +109,27 @@ def test_preconditioners_agree_at_config_4_size_over_a_transient():
         assert np.abs(pf - pc).max() <= 1e-10 * np.abs(pf).max()
     finally:
         P.close()
+
+
+def test_config_5_hundred_time_steps():
+    """BASELINE config 5 in full: 100 consecutive time steps on the 72^3 Q2/Q1 box ("100 timesteps transient, fixed-stress iteration count + wall-clock").
+    Two independent preconditioners (block fast diagonalisation, Chebyshev) walk the same transient: identical fixed-stress / pressure iteration counts in all 100
+    steps, every step does Krylov work, the CG counts stay bounded, and the final fields agree."""
+    P = box_problem(3, 72, 2)
+    runs = {}
+    try:
+        for name, prec in (("block_fdm", pk.PREC_FDM), ("chebyshev", pk.PREC_CHEBYSHEV)):
+            R = pk.Runner(P, device=0, operator_mode=pk.OP_MATRIX_FREE, p_init=REF["p_init"], dt=REF["dt"], abs_u=1e-12, rel_u=1e-10, max_it=50000, prec=prec, reduction=True)
+            R.initialize()
+            tr = [R.step()[0] for _ in range(100)]
+            runs[name] = (tr, R.ctx.get(pk.VEC_U), R.ctx.get(pk.VEC_P))
+            R.close()
+        (tf, uf, pf), (tc, uc, pc) = runs["block_fdm"], runs["chebyshev"]
+        for a, b in zip(tf, tc):
+            assert np.array_equal(a[:, :3], b[:, :3])
+            assert 0 < a[0, 6] <= 40 and 0 < b[0, 6] < 120
+        assert np.linalg.norm(uf - uc) <= 1e-6 * np.linalg.norm(uf)
+        assert np.abs(pf - pc).max() <= 1e-9 * np.abs(pf).max()
+        assert np.isfinite(uf).all() and np.isfinite(pf).all() and pf.max() > REF["p_init"]          # the injection well raises the pressure
+    finally:
+        P.close()
