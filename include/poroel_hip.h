@@ -290,7 +290,7 @@ int  poro_apply_preconditioner_u(poro_ctx *ctx, int32_t preconditioner, const do
 int  poro_bench_operator(poro_ctx *ctx, int which, int operator_mode, int reps, double *seconds_per_apply);
 /* accumulated HIP-event time (s) and launch count of the named kernel family since the last reset */
 int  poro_timers_reset(poro_ctx *ctx);            /* clears the accumulators and switches event timing on */
-int  poro_timers_enable(poro_ctx *ctx, int on);
+int  poro_timers_enable(poro_ctx *ctx, int on);   /* 0: off; 1: events on every launch; k > 1: on every k-th launch of a family (the events cost ~2.5 us per launch), poro_timers_get scales the sampled time to all launches */
 int  poro_timers_get(poro_ctx *ctx, const char *name, double *seconds, int64_t *launches);
 
 #ifdef __cplusplus

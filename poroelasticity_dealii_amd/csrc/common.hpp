@@ -102,7 +102,8 @@ struct ConsDev {
   bool any_inhom = false;
 };
 
-struct Timer { double seconds = 0; int64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+struct Timer { double seconds = 0; int64_t launches = 0 /* with events */, enqueued = 0 /* all */; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+               bool sample(int stride) { return enqueued++ % stride == 0; } };
 
 // interface of a general partition in one dof space (poro_partition.shared_*): concatenated per-neighbour lists for packing / receiving, and per
 // shared dof the sources of its sum in ascending rank order (-1 = this rank's own partial value, otherwise a position in `recv`)
@@ -169,6 +170,7 @@ struct poro_ctx {
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
+  int timing_stride = 1;   // events on every timing_stride-th launch of a family (poro_timers_enable)
   poro::DevBuf<poro::Cg1State> cg1_state; poro::DevBuf<double> cg1_z[2], cg1_w[2];   // single-reduction PCG of partitioned runs ([0]: displacement-sized, [1]: pressure-sized)
   bool matrix_built = false;
   int interleaved_u = 0;

@@ -122,7 +122,9 @@ struct Timed {
   poro_ctx *c; Timer *t = nullptr; hipEvent_t a = nullptr, b = nullptr;
   Timed(poro_ctx *c_, const char *name) : c(c_) {
     if (!c->timing) return;
-    t = &c->timers[name];
+    Timer *tt = &c->timers[name];
+    if (!tt->sample(c->timing_stride)) return;
+    t = tt;
     a = event_get(c); b = event_get(c); (void)hipEventRecord(a, c->stream);
   }
   ~Timed() { if (!t) return; (void)hipEventRecord(b, c->stream); t->pending.emplace_back(a, b); t->launches++; }
@@ -283,7 +285,7 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
   bool fused = false;
   if (mode == PORO_OP_MATRIX_FREE && c->box.enabled && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
     int slots;
-    if (c->timing) {   // events attached to the dispatch itself: the kernel's own duration, without the gaps to its neighbours in the stream
+    if (c->timing && c->timers["apply_u_matrix_free"].sample(c->timing_stride)) {   // events attached to the dispatch itself: the kernel's own duration, without the gaps to its neighbours in the stream
       Timer &t = c->timers["apply_u_matrix_free"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
       slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials, e0, e1, pcg_state);
       t.pending.emplace_back(e0, e1); t.launches++;
@@ -1345,7 +1347,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
             double *dp = (last && gz_partials) ? gz_partials : nullptr;
             if (dp) PORO_HIP(hipMemsetAsync(dp, 0, kMaxPartials * sizeof(double), s));
             int slots;
-            if (c->timing) { Timer &t = c->timers["apply_u_chebyshev_fused"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
+            if (c->timing && c->timers["apply_u_chebyshev_fused"].sample(c->timing_stride)) { Timer &t = c->timers["apply_u_chebyshev_fused"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
                              slots = kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, dp, e0, e1, pstate, &kc); t.pending.emplace_back(e0, e1); t.launches++; }
             else slots = kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, dp, nullptr, nullptr, pstate, &kc);
             if (dp && slots > 0) dot_done = true;
@@ -1637,14 +1639,16 @@ int poro_bench_operator(poro_ctx *c, int which, int operator_mode, int reps, dou
   });
 }
 
-int poro_timers_reset(poro_ctx *c) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); timers_collect(c); c->timers.clear(); c->timing = true; return 0; }); }
-int poro_timers_enable(poro_ctx *c, int on) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); timers_collect(c); c->timing = on != 0; return 0; }); }
+int poro_timers_reset(poro_ctx *c) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); timers_collect(c); c->timers.clear(); c->timing = true; c->timing_stride = 1; return 0; }); }
+int poro_timers_enable(poro_ctx *c, int on) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); timers_collect(c); c->timing = on != 0; c->timing_stride = on > 1 ? on : 1; return 0; }); }
 int poro_timers_get(poro_ctx *c, const char *name, double *seconds, int64_t *launches) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device)); timers_collect(c);
     auto it = c->timers.find(name);
-    if (seconds) *seconds = it == c->timers.end() ? 0.0 : it->second.seconds;
-    if (launches) *launches = it == c->timers.end() ? 0 : it->second.launches;
+    // sampled families: the measured time is scaled to all launches of the family (mean sampled duration x launches enqueued)
+    const bool have = it != c->timers.end() && it->second.launches > 0;
+    if (seconds) *seconds = have ? it->second.seconds * (double)std::max(it->second.enqueued, it->second.launches) / (double)it->second.launches : 0.0;
+    if (launches) *launches = it == c->timers.end() ? 0 : std::max(it->second.enqueued, it->second.launches);
     return 0;
   });
 }
