@@ -165,6 +165,7 @@ def load_host():
         L.poro_host_build_gmsh.restype = C.c_void_p
         L.poro_host_build_gmsh.argtypes = [C.c_char_p, C.c_int] + bc
         L.poro_host_set_pressure_bc.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
+        L.poro_host_tie_boundary.argtypes = [C.c_void_p, C.c_int, _ip, _ip]
         L.poro_host_partition.restype = C.c_void_p
         L.poro_host_partition.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.poro_host_local_to_global.restype = C.c_int64
@@ -264,6 +265,15 @@ class Problem:
             H.poro_host_local_to_global(h, space, a.ctypes.data_as(_ip))
             setattr(P, name, a)
         return P
+
+    def tie_boundary(self, conditions):
+        """extension: rigid frictionless plates [(boundary label, component)] - that displacement component takes one (unknown) value on the whole boundary;
+        ordinary entries x[dof] = x[master] of the displacement constraint list (poro_desc.cons_u)"""
+        lab, pl = _arr_i([c[0] for c in conditions]); comp, pc = _arr_i([c[1] for c in conditions])
+        if load_host().poro_host_tie_boundary(self.handle, len(conditions), pl, pc) != 0:
+            raise RuntimeError(load_host().poro_host_last_error().decode())
+        self.desc = self.desc_ptr.contents
+        return self
 
     def set_pressure_bc(self, conditions):
         """extension (the reference has no pressure boundary conditions): prescribed pressure [(boundary label, value)], e.g. a drained face p = 0"""

@@ -85,6 +85,18 @@ int poro_host_set_pressure_bc(void *h, int n, const int32_t *labels, const doubl
     return 0;
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+// extension: rigid frictionless plates - component `components[i]` of the displacement takes ONE (unknown) value on the boundary `labels[i]` (before the context is created)
+int poro_host_tie_boundary(void *h, int n, const int32_t *labels, const int32_t *components) {
+  try {
+    auto *P = static_cast<ProblemData *>(h);
+    if (P->part.n_ranks > 1) throw std::runtime_error("tie_boundary: implemented for one rank");
+    if (P->ties_added) throw std::runtime_error("tie_boundary: already applied");
+    P->bc.tie_labels.assign(labels, labels + n); P->bc.tie_components.assign(components, components + n);
+    for (int i = 0; i < n; ++i) if (components[i] < 0 || components[i] >= P->mesh.dim) throw std::runtime_error("tie_boundary: component out of range");
+    P->finalize(P->dofs.k_u, true);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 const poro_desc *poro_host_desc(void *h) { return &static_cast<ProblemData *>(h)->d; }
 void poro_host_free(void *h) { delete static_cast<ProblemData *>(h); }
 

@@ -185,6 +185,7 @@ struct BoundaryConditions {  // BoundaryConditions.h:6-62
   std::vector<int32_t> dirichlet_labels, dirichlet_components, neumann_labels, neumann_components;
   std::vector<double>  dirichlet_values, neumann_values;
   std::vector<int32_t> pressure_labels; std::vector<double> pressure_values;   // extension: prescribed pressure on whole boundary faces (drained boundary)
+  std::vector<int32_t> tie_labels, tie_components;   // extension: displacement component tied to ONE value on a boundary (rigid frictionless plate): x[dof] = x[master]
 };
 
 // VectorTools::interpolate_boundary_values(label, ConstantFunction(value), constraints, mask[component])
@@ -337,6 +338,7 @@ struct ProblemData {
   // general partition (partition_problem): interface lists and the local -> global maps of the piece
   std::vector<int32_t> part_neighbours, part_shared_u, part_shared_p, local_to_global_u, local_to_global_p;
   std::vector<int64_t> part_ptr_u, part_ptr_p;
+  bool ties_added = false;
   bool dirichlet_given = false;       // the Dirichlet list was filled by the caller (pieces of a partition: from the global list)
   poro_desc d{};
 
@@ -360,10 +362,30 @@ struct ProblemData {
     dirichlet_dof.clear(); dirichlet_value.clear();
     for (auto &kv : dir) { dirichlet_dof.push_back(kv.first); dirichlet_value.push_back(kv.second); }
   }
+  // extension: rigid-plate conditions.  All dofs of component comp on the faces labelled `label` that carry no boundary value are tied to the first of them
+  // (an ordinary entry of the constraint list: x[dof] = 1 * x[master]); the tractions of the tied rows then add up on the master (C^T b)
+  void add_ties() {
+    const int dim = mesh.dim, n1 = dofs.k_u + 1, ns = ipow(n1, dim);
+    for (size_t t = 0; t < bc.tie_labels.size(); ++t) {
+      std::vector<int32_t> on;
+      for (size_t bf = 0; bf < mesh.bface_cell.size(); ++bf) {
+        if (mesh.bface_id[bf] != bc.tie_labels[t]) continue;
+        const int64_t c = mesh.bface_cell[bf]; const int f = mesh.bface_local[bf], nd = f / 2, side = f % 2;
+        for (int s = 0; s < ns; ++s) { const int idx[3] = {s % n1, (s / n1) % n1, s / (n1 * n1)}; if (idx[nd] == side * dofs.k_u) on.push_back(dofs.cell_u[(c * ns + s) * dim + bc.tie_components[t]]); }
+      }
+      std::sort(on.begin(), on.end()); on.erase(std::unique(on.begin(), on.end()), on.end());
+      std::vector<int32_t> freed;
+      for (int32_t d : on) if (!std::binary_search(dirichlet_dof.begin(), dirichlet_dof.end(), d) && std::find(cons_u.dof.begin(), cons_u.dof.end(), d) == cons_u.dof.end()) freed.push_back(d);
+      for (size_t i = 1; i < freed.size(); ++i) {
+        cons_u.dof.push_back(freed[i]); cons_u.master.push_back(freed[0]); cons_u.weight.push_back(1.0); cons_u.inhom.push_back(0.0); cons_u.ptr.push_back((int64_t)cons_u.master.size());
+      }
+    }
+  }
   void finalize(int k_u, bool have_dofs = false) {
     if (!have_dofs) dofs = distribute_dofs(mesh, k_u);
     fe.build(mesh.dim, k_u);
     if (!dirichlet_given) make_dirichlet(mesh, dofs, bc, dirichlet_dof, dirichlet_value);
+    if (!ties_added && !bc.tie_labels.empty()) { add_ties(); ties_added = true; }
     close_constraints();
     d = poro_desc{};
     d.abi_version = PORO_ABI_VERSION; d.dim = mesh.dim; d.degree_u = k_u; d.degree_p = 1;
@@ -377,6 +399,7 @@ struct ProblemData {
     d.n_neumann = (int32_t)bc.neumann_labels.size();
     d.neumann_label = bc.neumann_labels.data(); d.neumann_component = bc.neumann_components.data(); d.neumann_value = bc.neumann_values.data();
     d.mat = mat; d.box = mesh.box;
+    if (cons_u.n() || cons_p.n()) d.box.enabled = 0;   // constraint lists run on the general operators (the structured kernels know Dirichlet conditions only)
     if (part.n_ranks == 0) { part.n_ranks = 1; part.rank = 0; }
     part.n_neighbours = (int32_t)part_neighbours.size();
     part.neighbour_rank = part_neighbours.data(); part.shared_ptr_u = part_ptr_u.data(); part.shared_dof_u = part_shared_u.data();
