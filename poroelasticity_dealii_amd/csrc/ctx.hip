@@ -1259,7 +1259,8 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
 int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec) {
   if (!c) return 0;
   if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
-  if (which_system == 0 ? c->cons_u.n : (c->cons_p.n || c->n_pdir)) return 0;   // condensed operators exist at operator level only: Jacobi
+  if (which_system == 0 && c->cons_u.n) return prec == PORO_PREC_CHEBYSHEV;      // condensed operators exist at operator level only: Jacobi and the polynomial built on it
+  if (which_system == 1 && (c->cons_p.n || c->n_pdir)) return 0;
   if (prec == PORO_PREC_SSOR || prec == PORO_PREC_ILU0) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
   if (prec == PORO_PREC_CHEBYSHEV) return which_system == 0;
   if (prec == PORO_PREC_FDM && which_system == 1) return fdm_p_supported(c);
@@ -1271,7 +1272,8 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     PORO_HIP(hipSetDevice(c->device));
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
-    if (c->cons_u.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE) throw Error("meshes with hanging-node constraints: PORO_PREC_JACOBI / NONE only (the operator is condensed on the fly)");
+    if (c->cons_u.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE && opts->preconditioner != PORO_PREC_CHEBYSHEV)
+      throw Error("meshes with constraint lists: PORO_PREC_JACOBI / CHEBYSHEV / NONE only (the operator is condensed on the fly)");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       if (mode != PORO_OP_CSR) throw Error("PORO_PREC_ILU0 needs the assembled CSR operator");
       const int rc = pcg_ilu0(c, c->Au, c->Au_val.p, c->ilu_u, c->ilu_u_valid, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);

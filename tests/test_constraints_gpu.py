@@ -40,8 +40,14 @@ def test_condensed_displacement_system(trio):
     assert rc0 == 0 and rc1 == 0 and info.iterations > 0
     assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-9
     assert not G.supports_preconditioner(0, pk.PREC_FDM) and not G.supports_preconditioner(0, pk.PREC_SSOR) and G.supports_preconditioner(0, pk.PREC_JACOBI)
-    with pytest.raises(RuntimeError, match="hanging-node"):
+    with pytest.raises(RuntimeError, match="constraint lists"):
         G.disp_solve(prec=pk.PREC_SSOR)
+    # the Chebyshev polynomial is built on the condensed operator and its Jacobi diagonal: same solution in fewer iterations
+    assert G.supports_preconditioner(0, pk.PREC_CHEBYSHEV)
+    G.fill(pk.VEC_U, 0.0)
+    rc2, info2 = G.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=50000, prec=pk.PREC_CHEBYSHEV)
+    assert rc2 == 0 and 0 < info2.iterations < info.iterations
+    assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-9
 
 
 def test_patch_test_on_device(trio):

@@ -60,7 +60,7 @@ def run(backend, nx, ny, deg, dt, steps):
             G = oracle_py.Oracle(P, hoisted=True)
             tr, _ = G.run(steps, p0, dt, prec=oracle_py.PREC_JACOBI, **KW)
         else:
-            tr, G = pk.run_problem(P, steps, p0, dt, operator_mode=pk.OP_MATRIX_FREE, prec=pk.PREC_JACOBI, **KW)     # constraint lists: general matrix-free operator condensed on the fly, Jacobi-CG
+            tr, G = pk.run_problem(P, steps, p0, dt, operator_mode=pk.OP_MATRIX_FREE, prec=pk.PREC_CHEBYSHEV, **KW)     # constraint lists: general matrix-free operator condensed on the fly, Chebyshev-CG
         p = G.get(pk.VEC_P)
         G.close()
         X = np.ctypeslib.as_array(P.desc.vertex_coords, shape=(P.desc.n_vertices, 2)).copy()
