@@ -118,12 +118,17 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
   const bool out = vn && lx >= 2 && lx <= TXN - 3 && !halo_wave;
   const bool bnd_xy = i == 0 || i == NX - 1 || j == 0 || j == NY - 1;
 
-  const unsigned n_nodes = (unsigned)NX * (unsigned)NY * (unsigned)NZ, nxy = (unsigned)NX * (unsigned)NY;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, n_nodes * 24u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(CHEB ? a.cheb.znew : y), 0, n_nodes * 24u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)a.nodemask, 0, a.constrained ? n_nodes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.cheb.g, 0, CHEB ? n_nodes * 24u : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.cheb.cls, 0, CHEB ? n_nodes : 0u, 0x00020000);
+  // the descriptors cover the planes THIS z-chunk touches (pbase .. pend - 1), so 32-bit offsets suffice for vectors of any length (kron_apply keeps a chunk's
+  // span below 2^31 bytes); a prefetch beyond pend is out of range and returns zeros like every other predicate
+  const unsigned nxy = (unsigned)NX * (unsigned)NY;
+  const int pbase = max(k0 - 2, 0), pend = min(k1 + 2, NZ);
+  const unsigned span_nodes = (unsigned)(pend - pbase) * nxy;
+  const size_t base_node = (size_t)pbase * nxy;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(x + 3 * base_node), 0, span_nodes * 24u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)((CHEB ? a.cheb.znew : y) + 3 * base_node), 0, span_nodes * 24u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.nodemask + base_node), 0, a.constrained ? span_nodes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(a.cheb.g + (CHEB ? 3 * base_node : 0)), 0, CHEB ? span_nodes * 24u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.cheb.cls + (CHEB ? base_node : 0)), 0, CHEB ? span_nodes : 0u, 0x00020000);
   const unsigned nxy_off = vn ? (unsigned)(j * NX + i) : kOOB;          // node offset inside a plane (invalid lanes: out of every buffer)
   const unsigned out_off = out ? (unsigned)(j * NX + i) : kOOB;
 
@@ -142,7 +147,7 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
   const bool mask_all = a.mask_anywhere != 0;
   auto load_plane = [&](int p, double (&v)[3], unsigned &m) {
     const bool pin = p >= 0 && p < NZ;                                   // wave-uniform
-    const unsigned node = (unsigned)p * nxy + nxy_off;
+    const unsigned node = (unsigned)(p - pbase) * nxy + nxy_off;       // relative to the chunk's first plane
     const unsigned off = (pin && vn) ? node * 24u : kOOB;
     bload3(rx, off, v);
     const bool mk = pin && vn && (mask_all || p == 0 || p == NZ - 1 || bnd_xy);
@@ -230,14 +235,14 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
 #endif
         return sacc;
       };
-      const unsigned d0b = ((unsigned)kk * nxy + out_off) * 24u;       // byte offset of the node's dofs; lanes without an output: out of range
+      const unsigned d0b = ((unsigned)(kk - pbase) * nxy + out_off) * 24u;       // byte offset of the node's dofs in the chunk; lanes without an output: out of range
       const unsigned so = out ? d0b : kOOB;
       // CHEB: x is the iterate z_j of the polynomial preconditioner in root form; instead of A z_j the kernel stores z_{j+1} = z_j + omega_j D^-1 (g - A z_j)
       // (omega_j = reciprocal of a root of the shifted Chebyshev polynomial; z_{j+1} goes to the other buffer of a ping-pong pair because neighbouring
       // tiles still read z_j) and accumulates g . z_{j+1}.  One extra read stream (g) instead of the two of the three-term recurrence.  Dirichlet dofs have
       // D^-1 = 0 and z = 0.  Lanes without an output load g = 0 and store nothing.
       const double *ctab = nullptr;
-      if constexpr (CHEB) ctab = a.cheb.tab + 3u * __builtin_amdgcn_raw_buffer_load_b8(rc, out ? (unsigned)kk * nxy + out_off : kOOB, 0, 0);
+      if constexpr (CHEB) ctab = a.cheb.tab + 3u * __builtin_amdgcn_raw_buffer_load_b8(rc, out ? (unsigned)(kk - pbase) * nxy + out_off : kOOB, 0, 0);
       auto emit = [&](int c, double v) {
         if constexpr (CHEB) {
           const double gi = bload1(rg, so + 8u * c);
@@ -385,17 +390,20 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
   const KronConsts &K = a.k;
 
   // bounds-checked buffer access as in kron_tile: halo / out-of-domain / unmasked conditions are out-of-range offsets, not branches
-  const unsigned n_nodes = (unsigned)NX * (unsigned)NY * (unsigned)NZ, nxy = (unsigned)NX * (unsigned)NY;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, n_nodes * 24u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(CHEB ? a.cheb.znew : y), 0, n_nodes * 24u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)a.nodemask, 0, a.constrained ? n_nodes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.cheb.g, 0, CHEB ? n_nodes * 24u : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)a.cheb.cls, 0, CHEB ? n_nodes : 0u, 0x00020000);
+  const unsigned nxy = (unsigned)NX * (unsigned)NY;
+  const int pbase = max(k0 - 1, 0), pend = min(k1 + 1, NZ);          // descriptors relative to the chunk's planes (see kron_tile)
+  const unsigned span_nodes = (unsigned)(pend - pbase) * nxy;
+  const size_t base_node = (size_t)pbase * nxy;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(x + 3 * base_node), 0, span_nodes * 24u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)((CHEB ? a.cheb.znew : y) + 3 * base_node), 0, span_nodes * 24u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.nodemask + base_node), 0, a.constrained ? span_nodes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(a.cheb.g + (CHEB ? 3 * base_node : 0)), 0, CHEB ? span_nodes * 24u : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.cheb.cls + (CHEB ? base_node : 0)), 0, CHEB ? span_nodes : 0u, 0x00020000);
   const unsigned nxy_off = vn ? (unsigned)(j * NX + i) : kOOB, out_off = out ? (unsigned)(j * NX + i) : kOOB;
   const bool mask_all = a.mask_anywhere != 0;
   auto load_plane = [&](int p, double (&v)[3], unsigned &m) {
     const bool pin = p >= 0 && p < NZ;
-    const unsigned node = (unsigned)p * nxy + nxy_off;
+    const unsigned node = (unsigned)(p - pbase) * nxy + nxy_off;
     bload3(rx, (pin && vn) ? node * 24u : kOOB, v);
     const bool mk = pin && vn && (mask_all || p == 0 || p == NZ - 1 || bnd_xy);
     m = __builtin_amdgcn_raw_buffer_load_b8(rm, mk ? node : kOOB, 0, 0);
@@ -446,9 +454,9 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
       const double t1 = FM - FK;
       return fma(cKx, FK, fma(cMx, FM, cDx * FD)) + wave_up1(t1 + FO) + wave_dn1(t1 - FO);   // from i-1 and i+1
     };
-    const unsigned so = out ? ((unsigned)kk * nxy + out_off) * 24u : kOOB;
+    const unsigned so = out ? ((unsigned)(kk - pbase) * nxy + out_off) * 24u : kOOB;
     const double *ctab = nullptr;
-    if constexpr (CHEB) ctab = a.cheb.tab + 3u * __builtin_amdgcn_raw_buffer_load_b8(rc, out ? (unsigned)kk * nxy + out_off : kOOB, 0, 0);
+    if constexpr (CHEB) ctab = a.cheb.tab + 3u * __builtin_amdgcn_raw_buffer_load_b8(rc, out ? (unsigned)(kk - pbase) * nxy + out_off : kOOB, 0, 0);
     auto emit = [&](int c, double v) {
       if constexpr (CHEB) {      // see kron_tile
         const double gi = bload1(rg, so + 8u * c);
@@ -690,7 +698,6 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
     else hipExtLaunchKernelGGL(k_kron2<1>, dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
     return (int)grid;
   }
-  if ((int64_t)a.nn[0] * a.nn[1] * a.nn[2] * 24 >= (int64_t)1 << 31) throw Error("structured operator: more than 2^31 bytes per displacement vector (32-bit buffer offsets)");
   // tile shapes: (64 lanes x 16 rows) and (32 x 32); valid outputs 60 x 12 / 28 x 28 for Q2 (halo 2), 62 x 14 / 30 x 30 for Q1 (halo 1)
   const int vx64 = ku == 2 ? 60 : 62, vx32 = ku == 2 ? 28 : 30, vy64 = ku == 2 ? 12 : 14, vy32 = ku == 2 ? 28 : 30, halo = ku == 2 ? 2 : 1;
   // x-extent = full 64-lane tiles + (when what is left fits) one 32-lane tile column
@@ -706,6 +713,11 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   const int units = a.nn[2] / a.zunit;
   const int upc = 8 / a.zunit;                                   // units in a chunk of 8 planes
   int nzc = n_cus / cols; if (nzc > (units + upc - 1) / upc) nzc = (units + upc - 1) / upc; if (nzc < 1) nzc = 1;
+  // 32-bit buffer offsets are relative to a chunk's first plane: a chunk (its planes + the halo + one prefetched pair) must span less than 2^31 bytes
+  { const int64_t plane_bytes = (int64_t)a.nn[0] * a.nn[1] * 24, max_planes = (((int64_t)1 << 31) - 1) / plane_bytes - 2 * halo - 3;
+    if (max_planes < 2 * a.zunit) throw Error("structured operator: an x-y plane of the box is too large for 32-bit buffer offsets");
+    const int need = (int)((a.nn[2] + max_planes - 1) / max_planes);
+    if (nzc < need) nzc = std::min(need, units); }
   a.nzc = nzc; a.zq = units / nzc; a.zr = units % nzc;
   a.nA = a.n64 * a.nty64 * a.nzc; a.nblocks = a.nA + a.has32 * a.nty32 * a.nzc; a.cols = cols;
   { static const int zm = std::getenv("PORO_KRON_COLMAJOR") ? 0 : 1; a.zmajor = zm; }
