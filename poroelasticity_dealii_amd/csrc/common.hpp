@@ -214,6 +214,7 @@ void la_cons_expand(hipStream_t s, const ConsDev &C, double *x, bool with_inhom)
 // y <- C^T y: y[master] += sum w y[dof_i], then y[dof_i] = 0 (ConstraintMatrix::condense of a vector)
 void la_cons_reduce(hipStream_t s, const ConsDev &C, double *y);
 void la_xpby(hipStream_t s, double *y, double a, double b, const double *x, int64_t n);   // y = a y + b x
+void la_ilu0_factor(hipStream_t s, const CsrDev &A, const SsorLevels &lv, double *lu /* in: A's values, out: L (unit diagonal) and U */, int *flag /* device int, 0 = ok, else 1 + row of a zero pivot */);
 void la_ilu_apply(hipStream_t s, const CsrDev &A, const double *lu, const SsorLevels &lv, const double *src, double *dst);
 void la_ssor_apply(hipStream_t s, const CsrDev &A, const double *val, const SsorLevels &lv, double omega, const double *src, double *dst);
 void la_sum_strains(hipStream_t s, double *ev, const double *const *strains, int n, int64_t len);

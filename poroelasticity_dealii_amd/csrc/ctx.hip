@@ -495,24 +495,18 @@ int pcg_ssor(poro_ctx *c, CsrDev &A, const double *val, double *x, const double 
                   [&](const double *gg, double *z) { la_ssor_apply(c->stream, A, val, A.ssor, om, gg, z); }, x, b, g, d, h, opts, info);
 }
 
-// ---- ILU(0): factorisation on the host (row-wise IKJ on A's own pattern), solves on the device ------------------------------------
+// ---- ILU(0): factorisation and solves on the device, both level-scheduled in the natural row order (la_ilu0_factor, la_ilu_apply) -----------------
 void ilu0_factor(poro_ctx *c, const CsrDev &A, const double *val, DevBuf<double> &lu_dev) {
-  std::vector<int64_t> rp(A.n + 1), dpos(A.n); std::vector<int32_t> col(A.nnz); std::vector<double> lu(A.nnz);
-  PORO_HIP(hipMemcpy(rp.data(), A.rp.p, (A.n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost)); PORO_HIP(hipMemcpy(col.data(), A.col.p, A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-  PORO_HIP(hipMemcpy(dpos.data(), A.diag_pos.p, A.n * sizeof(int64_t), hipMemcpyDeviceToHost)); PORO_HIP(hipMemcpy(lu.data(), val, A.nnz * sizeof(double), hipMemcpyDeviceToHost));
-  std::vector<int64_t> where(A.n, -1);                       // column -> position in the current row
-  for (int64_t i = 0; i < A.n; ++i) {
-    for (int64_t j = rp[i]; j < rp[i + 1]; ++j) where[col[j]] = j;
-    for (int64_t kk = rp[i]; kk < dpos[i]; ++kk) {
-      const int32_t k = col[kk];
-      const double lik = lu[kk] / lu[dpos[k]];
-      lu[kk] = lik;
-      for (int64_t jj = dpos[k] + 1; jj < rp[k + 1]; ++jj) { const int64_t pos = where[col[jj]]; if (pos >= 0) lu[pos] -= lik * lu[jj]; }
-    }
-    if (!(std::fabs(lu[dpos[i]]) > 0)) throw Error("ILU(0): zero pivot in row " + std::to_string(i));
-    for (int64_t j = rp[i]; j < rp[i + 1]; ++j) where[col[j]] = -1;
-  }
-  lu_dev.upload(lu);
+  std::vector<int64_t> rp(A.n + 1);
+  PORO_HIP(hipMemcpy(rp.data(), A.rp.p, (A.n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  int64_t longest = 0; for (int64_t i = 0; i < A.n; ++i) longest = std::max(longest, rp[i + 1] - rp[i]);
+  if (longest > 512) throw Error("ILU(0): rows longer than 512 entries are not supported by the device factorisation");
+  if (lu_dev.n < (size_t)A.nnz) lu_dev.alloc(A.nnz);
+  DevBuf<int> flag; flag.alloc(1); flag.zero(c->stream);
+  PORO_HIP(hipMemcpyAsync(lu_dev.p, val, A.nnz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  la_ilu0_factor(c->stream, A, A.ssor, lu_dev.p, flag.p);
+  int h = 0; PORO_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+  if (h) throw Error("ILU(0): zero pivot in row " + std::to_string(h - 1));
 }
 int pcg_ilu0(poro_ctx *c, CsrDev &A, const double *val, DevBuf<double> &lu, bool &valid, double *x, const double *b, double *g, double *d, double *h,
              const poro_solver_opts *opts, poro_solve_info *info) {

@@ -231,6 +231,36 @@ __global__ void k_ilu_bwd(int64_t n_lvl, const int32_t *__restrict__ rows, const
   for (int64_t j = dpos[r] + 1; j < rp[r + 1]; ++j) s -= lu[j] * dst[col[j]];
   dst[r] = s / lu[dpos[r]];
 }
+// ILU(0) factorisation, level-scheduled like the triangular solves: the rows of one level depend only on rows of earlier levels (launches), so they
+// factorise in parallel, ONE WAVE PER ROW.  The row lives in LDS while it is worked on (row-wise IKJ on A's own pattern, the pivots k in ascending order
+// exactly as a sequential sweep would take them; the products are rounded separately like the sequential reference, no fused multiply-add): for every
+// lower entry a_ik the lanes take the upper entries of row k, find their column in row i by binary search and subtract l_ik u_kj.
+constexpr int kIluMaxRow = 512;
+__global__ void __launch_bounds__(64)
+k_ilu0_level(int64_t n_lvl, const int32_t *__restrict__ rows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col, const int64_t *__restrict__ dpos, double *lu, int *flag) {
+  __shared__ double sval[kIluMaxRow];
+  __shared__ int32_t scol[kIluMaxRow];
+  const int lane = threadIdx.x;
+  const int32_t i = rows[blockIdx.x];
+  const int64_t r0 = rp[i]; const int len = (int)(rp[i + 1] - r0), nlow = (int)(dpos[i] - r0);
+  for (int t = lane; t < len; t += 64) { sval[t] = lu[r0 + t]; scol[t] = col[r0 + t]; }
+  __syncthreads();
+  for (int kk = 0; kk < nlow; ++kk) {
+    const int32_t k = scol[kk];
+    const double lik = sval[kk] / lu[dpos[k]];
+    __syncthreads();                                   // every lane has read a_ik before it is replaced by l_ik
+    if (lane == 0) sval[kk] = lik;
+    for (int64_t jj = dpos[k] + 1 + lane; jj < rp[k + 1]; jj += 64) {
+      const int32_t cj = col[jj];
+      int lo = kk + 1, hi = len - 1, pos = -1;           // columns are sorted and cj > k
+      while (lo <= hi) { const int mid = (lo + hi) >> 1; const int32_t cm = scol[mid]; if (cm == cj) { pos = mid; break; } if (cm < cj) lo = mid + 1; else hi = mid - 1; }
+      if (pos >= 0) sval[pos] = __dsub_rn(sval[pos], __dmul_rn(lik, lu[jj]));
+    }
+    __syncthreads();
+  }
+  if (lane == 0 && !(fabs(sval[nlow]) > 0)) atomicMax(flag, i + 1);     // zero pivot: report the (1-based) row
+  for (int t = lane; t < len; t += 64) lu[r0 + t] = sval[t];
+}
 __global__ void k_xpby(double *y, double a, double b, const double *x, int64_t n) {   // y = a y + b x
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] = a * y[i] + b * x[i];
 }
@@ -451,6 +481,12 @@ void la_ssor_apply(hipStream_t s, const CsrDev &A, const double *val, const Ssor
   for (size_t l = 0; l + 1 < lv.bwd_off.size(); ++l) {
     const int64_t n = lv.bwd_off[l + 1] - lv.bwd_off[l];
     hipLaunchKernelGGL(k_ssor_bwd, (unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, s, n, lv.bwd_rows.p + lv.bwd_off[l], A.rp.p, A.col.p, val, A.diag_pos.p, omega, dst);
+  }
+}
+void la_ilu0_factor(hipStream_t s, const CsrDev &A, const SsorLevels &lv, double *lu, int *flag) {
+  for (size_t l = 0; l + 1 < lv.fwd_off.size(); ++l) {
+    const int64_t n = lv.fwd_off[l + 1] - lv.fwd_off[l];
+    if (n) hipLaunchKernelGGL(k_ilu0_level, (unsigned)n, 64, 0, s, n, lv.fwd_rows.p + lv.fwd_off[l], A.rp.p, A.col.p, A.diag_pos.p, lu, flag);
   }
 }
 void la_ilu_apply(hipStream_t s, const CsrDev &A, const double *lu, const SsorLevels &lv, const double *src, double *dst) {

@@ -536,3 +536,47 @@ def test_box_regression_goldens_on_device():
             assert abs(np.linalg.norm(G.get(pk.VEC_U)) - g["u_l2"]) <= 1e-7 * g["u_l2"], name
         finally:
             G.close(); P.close()
+
+
+def test_device_ilu0_factors_equal_a_sequential_factorisation():
+    """the level-scheduled device factorisation (k_ilu0_level) takes the pivots of every row in the same order as a sequential IKJ sweep and rounds the products the same
+    way: ILU(0)-preconditioned CG, restated here in numpy on the exported matrix, takes the same number of iterations and lands on the same solution"""
+    P = box_problem(3, 3, 2)
+    G = pk.Context(P, 0, pk.OP_CSR)
+    try:
+        p = 10e6 * (1 + 0.1 * synth(G.n_p))
+        G.set(pk.VEC_P, p); G.disp_assemble_system(True)
+        rp, col, val = G.export_csr(pk.MAT_A_U)
+        b = G.get(pk.VEC_RHS_U); n = len(b)
+        lu = val.copy(); dpos = np.array([rp[i] + int(np.searchsorted(col[rp[i]:rp[i + 1]], i)) for i in range(n)])
+        for i in range(n):                                           # row-wise IKJ on A's own pattern
+            where = {int(c): j for j, c in zip(range(rp[i], rp[i + 1]), col[rp[i]:rp[i + 1]])}
+            for kk in range(rp[i], dpos[i]):
+                k = int(col[kk]); lik = lu[kk] / lu[dpos[k]]; lu[kk] = lik
+                for jj in range(dpos[k] + 1, rp[k + 1]):
+                    pos = where.get(int(col[jj]))
+                    if pos is not None:
+                        lu[pos] -= lik * lu[jj]
+        A = csr_to_scipy(rp, col, val)
+
+        def prec(g):
+            z = g.copy()
+            for i in range(n):
+                z[i] -= lu[rp[i]:dpos[i]] @ z[col[rp[i]:dpos[i]]]
+            for i in range(n - 1, -1, -1):
+                z[i] = (z[i] - lu[dpos[i] + 1:rp[i + 1]] @ z[col[dpos[i] + 1:rp[i + 1]]]) / lu[dpos[i]]
+            return z
+        x = np.zeros(n); g = A @ x - b; tol = 1e-12; it = 0
+        h = prec(g); d = -h; gh = g @ h
+        while np.sqrt(g @ g) > tol and it < 1000:                    # SolverCG's recurrence (g = A x - b)
+            it += 1
+            Ad = A @ d; alpha = gh / (d @ Ad); g = g + alpha * Ad; x = x + alpha * d
+            if np.sqrt(g @ g) <= tol:
+                break
+            h = prec(g); beta = gh; gh = g @ h; beta = gh / beta; d = -h + beta * d
+        rc, info = G.disp_solve(abs_tol=1e-12, max_iter=1000, prec=pk.PREC_ILU0)
+        assert rc == 0 and abs(info.iterations - it) <= 1, (info.iterations, it)
+        free = np.ones(n, bool); free[np.ctypeslib.as_array(P.desc.dirichlet_dof, shape=(P.desc.n_dirichlet,))] = False
+        assert rel2(G.get(pk.VEC_U)[free], x[free]) <= 1e-9
+    finally:
+        G.close(); P.close()
