@@ -284,7 +284,7 @@ def main():
         n_plain_useful = cg_total + solves
         n_apply, t_apply, n_launched = n_cheb_useful, t_cheb, n_cheb_launched
         alg_bytes = alg_plain + 8.0 * M["n_u_local"]
-        kernel_label = "k_kron3_q%d_cheb (matrix-free A_u z_j with the Chebyshev root-form update z_{j+1} = z_j + omega_j D^-1 (g - A z_j) fused into the stores)" % deg
+        kernel_label = ("k_kron3_q%d_cheb" % deg if dim == 3 else "k_kron2<%d, true>" % deg) + " (matrix-free A_u z_j with the Chebyshev root-form update z_{j+1} = z_j + omega_j D^-1 (g - A z_j) fused into the stores)"
     else:
         n_apply = int(work["apply_u"]) or n_plain_launched
         n_plain_useful = n_apply; t_apply, n_launched = t_plain, n_plain_launched

@@ -1323,7 +1323,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         int lo = 0, hi = m; while (lo <= hi) { roots.push_back(r[hi--]); if (lo <= hi) roots.push_back(r[lo++]); } }
       if (!c->cheb_z.p) { c->cheb_z.alloc(c->n_u); c->cheb_z.zero(c->stream); c->cheb_t.alloc(c->n_u); c->cheb_t.zero(c->stream); }
       if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
-      const bool fuse = mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && c->dim == 3 && kron_supported(c->dim, c->k_u) && !c->comm.multi() && c->diag_u_cls.p && !c->cons_u.n &&
+      const bool fuse = mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && c->box.enabled && kron_supported(c->dim, c->k_u) && !c->comm.multi() && c->diag_u_cls.p && !c->cons_u.n &&
                         !std::getenv("PORO_CHEB_UNFUSED");
       const int64_t n_own = owned(c, c->n_u, c->comm.part.plane_u);
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *gz_partials) {

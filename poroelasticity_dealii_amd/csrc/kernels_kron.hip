@@ -555,7 +555,7 @@ k_kron3_q1_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y
 //      A_xy = l Cx (x) Cy^T + G Cx^T (x) Cy,  A_yx = A_xy^T.   No march: one 64 x 16 tile per trip, the two components of the tile go through
 // LDS for the y-stage (one row per wave), the x-stage is the same scatter-by-DPP as in 3D.  A workgroup loops over tiles when the fused
 // dot product limits the grid to the number of partial slots.
-template <int KU> __global__ void __launch_bounds__(1024)
+template <int KU, bool CHEB> __global__ void __launch_bounds__(1024)
 k_kron2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   constexpr int H = KU == 2 ? 2 : 1, VX = 64 - 2 * H, VY = 16 - 2 * H;
   __shared__ double L[2 * 16 * 64];
@@ -617,7 +617,14 @@ k_kron2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
       // K.xk_* = (l+2G | G) sKx sMy, K.m_lKyMz / m_gKyMz = (l+2G | G) sMx sKy, K.cc_mz = {-(l+G), l-G, G-l, l+G} sC^2
       const double yx = xstage(K.xk_l2g * My[0], K.m_gKyMz * Ky[0], fma(K.cc_mz[1], Dy[1], K.cc_mz[0] * Oy[1]), fma(K.cc_mz[3], Dy[1], K.cc_mz[2] * Oy[1]));
       const double yy = xstage(K.xk_g * My[1], K.m_lKyMz * Ky[1], fma(K.cc_mz[2], Dy[0], K.cc_mz[0] * Oy[0]), fma(K.cc_mz[3], Dy[0], K.cc_mz[1] * Oy[0]));
-      if (out) { y[node * 2] = yx; y[node * 2 + 1] = yy; dot_acc = fma(u[0], yx, fma(u[1], yy, dot_acc)); }
+      if (out) {
+        if constexpr (CHEB) {   // the Chebyshev root-form update where the product leaves the registers (see kron_tile): z_{j+1} = z_j + omega_j D^-1 (g - A z_j), g . z_{j+1}
+          const double *ctab = a.cheb.tab + 2u * a.cheb.cls[node];
+          const double g0 = a.cheb.g[node * 2], g1 = a.cheb.g[node * 2 + 1];
+          const double z0 = fma(a.cheb.omega * ctab[0], g0 - yx, u[0]), z1 = fma(a.cheb.omega * ctab[1], g1 - yy, u[1]);
+          a.cheb.znew[node * 2] = z0; a.cheb.znew[node * 2 + 1] = z1; dot_acc = fma(g0, z0, fma(g1, z1, dot_acc));
+        } else { y[node * 2] = yx; y[node * 2 + 1] = yy; dot_acc = fma(u[0], yx, fma(u[1], yy, dot_acc)); }
+      }
     }
     if (tile + (int)gridDim.x < ntiles) __syncthreads();
   }
@@ -694,8 +701,12 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
     for (int i = 0; i < 4; ++i) a.k.cc_mz[i] = c[i] * sC * sC;
     a.nodemask = m.nodemask; a.constrained = constrained ? 1 : 0; a.mask_anywhere = m.mask_anywhere; a.dot_partials = dot_partials; a.pcg = pcg;
     const unsigned grid = (unsigned)(dot_partials ? std::min<int64_t>(ntiles, kMaxPartials) : ntiles);
-    if (ku == 2) hipExtLaunchKernelGGL(k_kron2<2>, dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
-    else hipExtLaunchKernelGGL(k_kron2<1>, dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
+    if (cheb) {
+      a.cheb = *cheb;
+      if (ku == 2) hipExtLaunchKernelGGL((k_kron2<2, true>), dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
+      else hipExtLaunchKernelGGL((k_kron2<1, true>), dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
+    } else if (ku == 2) hipExtLaunchKernelGGL((k_kron2<2, false>), dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
+    else hipExtLaunchKernelGGL((k_kron2<1, false>), dim3(grid), dim3(1024), 0, s, ev0, ev1, 0, a, x, y);
     return (int)grid;
   }
   // tile shapes: (64 lanes x 16 rows) and (32 x 32); valid outputs 60 x 12 / 28 x 28 for Q2 (halo 2), 62 x 14 / 30 x 30 for Q1 (halo 1)

@@ -18,7 +18,7 @@ def solve(G, prec, **kw):
     return G.get(pk.VEC_U), info
 
 
-@pytest.mark.parametrize("dim,n,deg,mode", [(3, 6, 2, pk.OP_MATRIX_FREE), (3, (7, 5, 6), 1, pk.OP_MATRIX_FREE), (2, 12, 2, pk.OP_MATRIX_FREE), (3, 4, 2, pk.OP_CSR), (2, 10, 1, pk.OP_CSR)], ids=str)
+@pytest.mark.parametrize("dim,n,deg,mode", [(3, 6, 2, pk.OP_MATRIX_FREE), (3, (7, 5, 6), 1, pk.OP_MATRIX_FREE), (2, 12, 2, pk.OP_MATRIX_FREE), (2, (9, 14), 1, pk.OP_MATRIX_FREE), (3, 4, 2, pk.OP_CSR), (2, 10, 1, pk.OP_CSR)], ids=str)
 def test_chebyshev_cg_matches_the_oracle(dim, n, deg, mode, monkeypatch):
     P = box_problem(dim, n, deg)
     O = oracle_py.Oracle(P, hoisted=True)
@@ -36,8 +36,8 @@ def test_chebyshev_cg_matches_the_oracle(dim, n, deg, mode, monkeypatch):
             assert ic.iterations < ij.iterations and ic.operator_applications == (m + 1) * (ic.iterations + 1)
             print(f"{dim}D n={n} Q{deg} m={m}: Chebyshev {ic.iterations} its / {ic.operator_applications} applications, Jacobi {ij.iterations} its")
             assert ic.operator_applications <= 1.7 * ij.operator_applications        # the polynomial costs few extra operator applications
-        if mode == pk.OP_MATRIX_FREE and dim == 3:
-            # the fused recurrence (inside k_kron3_*) against the elementwise kernel after the plain operator
+        if mode == pk.OP_MATRIX_FREE:
+            # the fused recurrence (inside k_kron3_* / k_kron2) against the elementwise kernel after the plain operator
             monkeypatch.setenv("PORO_CHEB_UNFUSED", "1")
             uu, iu = solve(G, pk.PREC_CHEBYSHEV, poly_degree=4)
             monkeypatch.delenv("PORO_CHEB_UNFUSED")
