@@ -366,7 +366,7 @@ int pcg_single_reduction(poro_ctx *c, const std::function<bool(const double *, d
 // when it has already left the block partials of g . z (over the owned rows) in gz_partials.
 int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
         const DiagVec &diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info,
-        const std::function<bool(const double *, double *, double *)> *precond = nullptr, int *its_hint = nullptr) {
+        const std::function<bool(const double *, double *, double *)> *precond = nullptr, int *its_hint = nullptr, bool precond_gated = false) {
   static const bool two_reductions = std::getenv("PORO_TWO_REDUCTION_CG") != nullptr;    // A/B hook: the three-kernel recurrence on partitioned runs too
   if (c->comm.multi() && !two_reductions) return pcg_single_reduction(c, apply, n, plane, x, b, diag, g, d, h, opts, info, precond, its_hint);
   hipStream_t s = c->stream;
@@ -390,15 +390,16 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   pcg_scalars_start(s, sc, red, opts->abs_tol, opts->rel_tol, opts->max_iter, opts->stop_rule);
   PORO_HIP(hipMemsetAsync(part_dh, 0, kMaxPartials * sizeof(double), s));
   PcgScalars hs{};
-  int batch = precond ? 1 : 4, it = 0;   // an explicit preconditioner is expensive and strong: poll after every iteration at first
-  // expected iteration count: linear extrapolation of the last two solves of this system (a transient's warm-started counts drift steadily)
+  int it = 0;
+  // Iterations are enqueued in batches, THEN the device-side state is polled (a host round trip idles the GPU for ~50 us).  Launches behind the finishing
+  // iteration are no-ops (the vector kernels, the structured operator and the fused Chebyshev kernels test the device-side flag; ~1 us each), so where
+  // everything is gated an overshoot is cheaper than a poll; an ungated explicit preconditioner (fast diagonalisation) is not, so its batches stop short.
+  // Expected iteration count: linear extrapolation of the last two solves of this system (a transient's warm-started counts drift steadily).
   int expect = 0;
   if (its_hint && its_hint[0] > 0) { expect = its_hint[1] > 0 ? 2 * its_hint[0] - its_hint[1] : its_hint[0]; expect = std::max(expect, its_hint[0] / 2); }
-  auto next_batch = [&](int done_its) { const int left = expect - 6 - done_its; return left >= 4 ? std::min(32, left) : 3; };
-  if (expect > 0) batch = next_batch(0);
+  const bool cheap_overshoot = !precond || precond_gated;
+  int batch = expect > 0 ? (cheap_overshoot ? std::min(expect + 1, 256) : std::max(1, expect - 1)) : (precond ? 1 : 4);
   while (true) {
-    PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
-    if (hs.done || hs.finishing) break;
     for (int k = 0; k < batch; ++k) {
       ++it;
       // operator (+ fused or separate d.h partials).  A fused dot runs over ALL local rows of the pre-exchange partial product, which
@@ -411,10 +412,9 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
       if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
       pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
-    // iterations are enqueued in batches between polls of the device-side state.  Launches behind the finishing iteration are no-ops;
-    // a warm-started solve takes about as many iterations as the previous one, so with a hint the big batches stop a few iterations
-    // short of it and the tail is polled in pairs (few no-op launches, few host round trips)
-    if (expect > 0) batch = next_batch(it);
+    PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+    if (hs.done || hs.finishing) break;
+    if (expect > 0) batch = cheap_overshoot ? 4 : 1;
     else if (batch < 32) batch *= 2;
   }
   if (its_hint) { its_hint[1] = its_hint[0]; its_hint[0] = hs.it; }
@@ -1359,7 +1359,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       DiagVec dz = dj; dz.z = c->wz_u.p;
       dz.z1_out = (m % 2 == 0) ? c->wz_u.p : c->cheb_z.p; dz.z1_scale = 1.0 / roots[0];
       const int64_t applies0 = c->cheb_applies;
-      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_cheb_u);
+      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_cheb_u, fuse);
       // useful operator applications: one per CG iteration + the initial residual, and m per preconditioner call (one call per iteration + the first direction)
       if (info) info->operator_applications = (int64_t)info->iterations + 1 + (int64_t)m * (info->iterations + 1);
       (void)applies0;
