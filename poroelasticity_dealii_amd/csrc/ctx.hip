@@ -398,7 +398,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   int expect = 0;
   if (its_hint && its_hint[0] > 0) { expect = its_hint[1] > 0 ? 2 * its_hint[0] - its_hint[1] : its_hint[0]; expect = std::max(expect, its_hint[0] / 2); }
   const bool cheap_overshoot = !precond || precond_gated;
-  int batch = expect > 0 ? (cheap_overshoot ? std::min(expect + 1, 256) : std::max(1, expect - 1)) : (precond ? 1 : 4);
+  int batch = expect > 0 ? (cheap_overshoot ? std::min(expect, 256) : std::max(1, expect - 1)) : (precond ? 1 : 4);   // (a repeated step hits `expect` exactly: no launch behind the end)
   while (true) {
     for (int k = 0; k < batch; ++k) {
       ++it;
@@ -414,7 +414,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
     }
     PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
     if (hs.done || hs.finishing) break;
-    if (expect > 0) batch = cheap_overshoot ? 4 : 1;
+    if (expect > 0) batch = cheap_overshoot ? 3 : 1;
     else if (batch < 32) batch *= 2;
   }
   if (its_hint) { its_hint[1] = its_hint[0]; its_hint[0] = hs.it; }
