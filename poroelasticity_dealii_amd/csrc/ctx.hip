@@ -329,7 +329,7 @@ int pcg_single_reduction(poro_ctx *c, const std::function<bool(const double *, d
   la_fill(s, d, 0.0, n); la_fill(s, sv, 0.0, n);
   Cg1State hs{};
   int expect = 0, enq = 0;
-  if (its_hint && its_hint[0] > 0) { expect = its_hint[1] > 0 ? 2 * its_hint[0] - its_hint[1] : its_hint[0]; expect = std::max(expect, its_hint[0] / 2); }
+  if (its_hint && its_hint[0] > 0) { expect = its_hint[1] > 0 ? 2 * its_hint[0] - its_hint[1] : its_hint[0]; expect = std::min(std::max(expect, its_hint[0] / 2), its_hint[0]); }   // (never above the last count: nothing here is gated)
   auto next_batch = [&](int done_its) { const int left = expect - 4 - done_its; return left >= 4 ? std::min(32, left) : 2; };
   int batch = expect > 0 ? next_batch(0) : 1;
   while (true) {
@@ -398,6 +398,9 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   int expect = 0;
   if (its_hint && its_hint[0] > 0) { expect = its_hint[1] > 0 ? 2 * its_hint[0] - its_hint[1] : its_hint[0]; expect = std::max(expect, its_hint[0] / 2); }
   const bool cheap_overshoot = !precond || precond_gated;
+  // the extrapolation must not run away after an atypical solve (a warm restart that took 3 iterations, followed by a real step): never expect more than a quarter
+  // above the last count, and nothing above it where an overshoot is expensive
+  if (expect > 0) expect = std::min(expect, cheap_overshoot ? its_hint[0] + std::max(2, its_hint[0] / 4) : its_hint[0]);
   int batch = expect > 0 ? (cheap_overshoot ? std::min(expect, 256) : std::max(1, expect - 1)) : (precond ? 1 : 4);   // (a repeated step hits `expect` exactly: no launch behind the end)
   while (true) {
     for (int k = 0; k < batch; ++k) {
