@@ -39,5 +39,10 @@ PORO_DIAG_SKIP_SELFCHECK=1 python3 $ROOT/tools/asm_bench.py 3,32,2 3,48,2 3,72,2
 python3 $ROOT/tools/fdmu_bench.py > $OUT/${TAG}_fdmu_apply.txt 2>&1
 python3 $ROOT/bench.py --dim 3 --degree 1 --cells 99 --no-cpu-baseline > $OUT/${TAG}_bench_line_c3.json 2>/dev/null
 python3 $ROOT/bench.py --dim 2 --cells 336 --no-cpu-baseline > $OUT/${TAG}_bench_line_c2.json 2>/dev/null
-rm -rf $OUT/stats_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
+# where the GPU idles inside a step (host round trips): kernel trace of the headline run without per-dispatch events
+rocprofv3 --kernel-trace --output-format csv -d $OUT/ktrace_$TAG -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-variants --no-weak-line --no-cpu-baseline --no-kernel-events > /dev/null 2>&1
+python3 $ROOT/tools/gap_analysis.py $(ls $OUT/ktrace_$TAG/*/*kernel_trace.csv | head -1) 4 > $OUT/${TAG}_gpu_idle_gaps.txt
+python3 $ROOT/tools/step_times.py 8 > $OUT/${TAG}_step_times.txt 2>/dev/null
+bash $ROOT/tools/sq_counters.sh $TAG > /dev/null 2>&1 && cp $ROOT/gpurun_out/sq_$TAG/summary.txt $OUT/${TAG}_sq_counters_kron3.txt
+rm -rf $OUT/stats_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG $OUT/ktrace_$TAG
 ls -la $OUT
