@@ -171,6 +171,7 @@ struct poro_ctx {
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
   int timing_stride = 1;   // events on every timing_stride-th launch of a family (poro_timers_enable)
+  poro::DevBuf<double> cheb_side_lo, cheb_side_hi;   // partial products of the fused Chebyshev kernel on the shared planes (slab partitions)
   poro::DevBuf<poro::Cg1State> cg1_state; poro::DevBuf<double> cg1_z[2], cg1_w[2];   // single-reduction PCG of partitioned runs ([0]: displacement-sized, [1]: pressure-sized)
   bool matrix_built = false;
   int interleaved_u = 0;
@@ -209,6 +210,8 @@ void la_pointwise_mul(hipStream_t s, double *y, const double *x, int64_t n);   /
 // gz_partials != nullptr: block partials of g . z_new over the first n_owned entries
 void la_cheb_first(hipStream_t s, double *z, const double *g, const DiagVec &dv, double scale, int64_t n);
 void la_cheb_step(hipStream_t s, double *znew, const double *zj, const double *g, const double *Az, const DiagVec &dv, double omega, int64_t n, int64_t n_owned, double *gz_partials);
+// shared planes of a slab partition after the fused kernel: z_{j+1} = z_j + omega D^-1 (g - (own partial + neighbour's partial)) on the first (lo) / last (hi) `plane` dofs of a vector of n
+void la_cheb_fix_planes(hipStream_t s, double *znew, const double *zj, const double *g, const double *own_lo, const double *nbr_lo, const double *own_hi, const double *nbr_hi, const DiagVec &dv, double omega, int64_t n, int64_t plane);
 // x[dof_i] = sum_k w_k x[master_k] (+ inhomogeneity_i): ConstraintMatrix::distribute; with_inhom = false inside the Krylov iteration
 void la_cons_expand(hipStream_t s, const ConsDev &C, double *x, bool with_inhom);
 // y <- C^T y: y[master] += sum w y[dof_i], then y[dof_i] = 0 (ConstraintMatrix::condense of a vector)
@@ -267,7 +270,9 @@ void p_stencil_apply(hipStream_t s, int dim, const BoxDev &box, double a, double
 void p_residual_stencil(hipStream_t s, int dim, const BoxDev &box, double kappa, const double *t, const double *p, const double *src, double *R);
 
 // polynomial-preconditioner step fused into the structured operator's stores: z_new = z_j + omega D^-1 (g - A z_j), D^-1 in dictionary form; z_new != z_j
-struct KronCheb { const double *g = nullptr; double *znew = nullptr; double omega = 0; const uint8_t *cls = nullptr; const double *tab = nullptr; };
+struct KronCheb { const double *g = nullptr; double *znew = nullptr; double omega = 0; const uint8_t *cls = nullptr; const double *tab = nullptr;
+                  // slab partitions: the raw partial product A z_j on the first / last node plane (the planes shared with the lower / upper neighbour) is written here as well
+                  double *side_lo = nullptr, *side_hi = nullptr; };
 // ---- kernels_kron.hip: sum-factorised (Kronecker) form of the same operator ---------------------------
 bool kron_supported(int dim, int k_u);
 void kron_prepare_device();   // per-device function attributes (dynamic LDS opt-in) of the structured kernels; call after hipSetDevice

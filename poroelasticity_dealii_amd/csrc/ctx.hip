@@ -205,30 +205,35 @@ void exchange_add_general(poro_ctx *c, double *v, int64_t n) {
   } else throw Error("partitioned context without a communicator (call poro_ctx_comm_init_* first)");
   la_ifc_sum(c->stream, I, v);
 }
-void exchange_add(poro_ctx *c, double *v, int64_t n, int64_t plane) {
+// slab partitions: send the planes `send_lo` / `send_hi` to the lower / upper neighbour, receive theirs into comm.recv_lo / recv_hi (one grouped exchange)
+void exchange_planes(poro_ctx *c, const double *send_lo, const double *send_hi, int64_t plane) {
   Comm &cm = c->comm;
-  if (!cm.multi()) return;
-  Timed tm(c, "halo_exchange");
-  if (cm.general) { exchange_add_general(c, v, n); return; }
   if (cm.recv_lo.n < (size_t)plane) { cm.recv_lo.alloc(plane); cm.recv_hi.alloc(plane); }
   if (cm.nccl_comm) {
     ncclComm_t comm = (ncclComm_t)cm.nccl_comm;
     PORO_NCCL(g_rccl.GroupStart());
-    if (cm.part.has_upper) { PORO_NCCL(g_rccl.Send(v + n - plane, plane, ncclFloat64, cm.part.rank + 1, comm, c->stream)); PORO_NCCL(g_rccl.Recv(cm.recv_hi.p, plane, ncclFloat64, cm.part.rank + 1, comm, c->stream)); }
-    if (cm.part.has_lower) { PORO_NCCL(g_rccl.Send(v, plane, ncclFloat64, cm.part.rank - 1, comm, c->stream)); PORO_NCCL(g_rccl.Recv(cm.recv_lo.p, plane, ncclFloat64, cm.part.rank - 1, comm, c->stream)); }
+    if (cm.part.has_upper) { PORO_NCCL(g_rccl.Send(send_hi, plane, ncclFloat64, cm.part.rank + 1, comm, c->stream)); PORO_NCCL(g_rccl.Recv(cm.recv_hi.p, plane, ncclFloat64, cm.part.rank + 1, comm, c->stream)); }
+    if (cm.part.has_lower) { PORO_NCCL(g_rccl.Send(send_lo, plane, ncclFloat64, cm.part.rank - 1, comm, c->stream)); PORO_NCCL(g_rccl.Recv(cm.recv_lo.p, plane, ncclFloat64, cm.part.rank - 1, comm, c->stream)); }
     PORO_NCCL(g_rccl.GroupEnd());
   } else if (cm.sr) {
     cm.hsend.resize(plane); cm.hrecv.resize(plane);
-    auto one = [&](double *dev_send, double *dev_recv, int peer) {
+    auto one = [&](const double *dev_send, double *dev_recv, int peer) {
       PORO_HIP(hipMemcpyAsync(cm.hsend.data(), dev_send, plane * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       PORO_HIP(hipStreamSynchronize(c->stream));
       cm.sr(cm.hsend.data(), cm.hrecv.data(), plane, peer, cm.user);
       PORO_HIP(hipMemcpyAsync(dev_recv, cm.hrecv.data(), plane * sizeof(double), hipMemcpyHostToDevice, c->stream));
       PORO_HIP(hipStreamSynchronize(c->stream));
     };
-    if (cm.part.has_upper) one(v + n - plane, cm.recv_hi.p, cm.part.rank + 1);
-    if (cm.part.has_lower) one(v, cm.recv_lo.p, cm.part.rank - 1);
+    if (cm.part.has_upper) one(send_hi, cm.recv_hi.p, cm.part.rank + 1);
+    if (cm.part.has_lower) one(send_lo, cm.recv_lo.p, cm.part.rank - 1);
   } else throw Error("partitioned context without a communicator (call poro_ctx_comm_init_* first)");
+}
+void exchange_add(poro_ctx *c, double *v, int64_t n, int64_t plane) {
+  Comm &cm = c->comm;
+  if (!cm.multi()) return;
+  Timed tm(c, "halo_exchange");
+  if (cm.general) { exchange_add_general(c, v, n); return; }
+  exchange_planes(c, v, v + n - plane, plane);
   la_add_two_ranges(c->stream, cm.part.has_upper ? v + n - plane : nullptr, cm.recv_hi.p, cm.part.has_lower ? v : nullptr, cm.recv_lo.p, plane);
 }
 void allreduce_sum(poro_ctx *c, double *dev, int n) {
@@ -1326,8 +1331,12 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         int lo = 0, hi = m; while (lo <= hi) { roots.push_back(r[hi--]); if (lo <= hi) roots.push_back(r[lo++]); } }
       if (!c->cheb_z.p) { c->cheb_z.alloc(c->n_u); c->cheb_z.zero(c->stream); c->cheb_t.alloc(c->n_u); c->cheb_t.zero(c->stream); }
       if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
-      const bool fuse = mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && c->box.enabled && kron_supported(c->dim, c->k_u) && !c->comm.multi() && c->diag_u_cls.p && !c->cons_u.n &&
-                        !std::getenv("PORO_CHEB_UNFUSED");
+      const bool fusable = mode == PORO_OP_MATRIX_FREE && c->mf_variant == 1 && c->box.enabled && kron_supported(c->dim, c->k_u) && c->diag_u_cls.p && !c->cons_u.n && !std::getenv("PORO_CHEB_UNFUSED");
+      const bool fuse = fusable && !c->comm.multi();
+      // slab partitions (3D): the fused kernel runs on every rank with its LOCAL partial product; on the two shared node planes it also leaves the raw partial, the neighbours
+      // swap those planes and a plane-sized kernel redoes the update there with the complete sum (the same two numbers on both ranks: bitwise equal copies)
+      const bool fuse_multi = fusable && c->comm.multi() && !c->comm.general && c->dim == 3;
+      if (fuse_multi && c->cheb_side_lo.n < (size_t)c->comm.part.plane_u) { c->cheb_side_lo.alloc(c->comm.part.plane_u); c->cheb_side_hi.alloc(c->comm.part.plane_u); }
       const int64_t n_own = owned(c, c->n_u, c->comm.part.plane_u);
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *gz_partials) {
         Timed tm(c, "precondition_u_chebyshev");
@@ -1341,7 +1350,19 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
           const double omega = 1.0 / roots[j];
           double *zj = X[(j - 1) & 1], *zn = X[j & 1];
           const bool last = j == m;
-          if (fuse) {
+          if (fuse_multi) {
+            const poro_partition &pt = c->comm.part; const int64_t plane = pt.plane_u;
+            KronCheb kc; kc.g = g; kc.znew = zn; kc.omega = omega; kc.cls = c->diag_u_cls.p; kc.tab = c->diag_u_tab.p;
+            kc.side_lo = pt.has_lower ? c->cheb_side_lo.p : nullptr; kc.side_hi = pt.has_upper ? c->cheb_side_hi.p : nullptr;
+            if (c->timing && c->timers["apply_u_chebyshev_fused"].sample(c->timing_stride)) { Timer &t = c->timers["apply_u_chebyshev_fused"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
+                                                                                           (void)kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, nullptr, e0, e1, nullptr, &kc); t.pending.emplace_back(e0, e1); t.launches++; }
+            else (void)kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, nullptr, nullptr, nullptr, nullptr, &kc);
+            if (pt.has_lower || pt.has_upper) {
+              { Timed te(c, "halo_exchange"); exchange_planes(c, c->cheb_side_lo.p, c->cheb_side_hi.p, plane); }
+              la_cheb_fix_planes(s, zn, zj, g, kc.side_lo, c->comm.recv_lo.p, kc.side_hi, c->comm.recv_hi.p, dj, omega, c->n_u, plane);
+            }
+            if (last && gz_partials) { la_dot_partials(s, g, zn, n_own, gz_partials); dot_done = true; }
+          } else if (fuse) {
             KronCheb kc; kc.g = g; kc.znew = zn; kc.omega = omega; kc.cls = c->diag_u_cls.p; kc.tab = c->diag_u_tab.p;
             double *dp = (last && gz_partials) ? gz_partials : nullptr;
             if (dp) PORO_HIP(hipMemsetAsync(dp, 0, kMaxPartials * sizeof(double), s));

@@ -99,7 +99,7 @@ __device__ inline void bload3(__amdgpu_buffer_rsrc_t r, unsigned off, double (&v
 __device__ inline double bload1(__amdgpu_buffer_rsrc_t r, unsigned off) { const v2u u = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); return __hiloint2double(u.y, u.x); }
 __device__ inline void bstore1(__amdgpu_buffer_rsrc_t r, unsigned off, double v) { v2u u; u.x = __double2loint(v); u.y = __double2hiint(v); __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0); }
 
-template <int TXN, bool CHEB>
+template <int TXN, int CHEB>   // CHEB: 0 plain operator, 1 fused Chebyshev update, 2 the same + raw partial product on the first / last plane (slab partitions)
 __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__restrict__ x, double *__restrict__ y, double *L, const int X0, const int tyi, const int zc) {
   constexpr int RPW = 64 / TXN, TYR = 16 * RPW, VY = TYR - 4;   // rows per wave, rows per tile, valid rows
   static_assert(TXN * TYR == kTileNodes, "tile");
@@ -322,7 +322,14 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
       __syncthreads();   // slots 0..2 must not be overwritten by a fast wave's plane kk+2 before everybody has read wz (same buffer)
       if (halo_wave) return;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) emit(c, xstage(XK[c], XM[c], XO[c], XD[c]));
+      for (int c = 0; c < 3; ++c) {
+        const double v = xstage(XK[c], XM[c], XO[c], XD[c]);
+        if constexpr (CHEB == 2) {   // slab partitions: the raw partial product on the planes shared with the neighbours goes to a side buffer as well (ctx.hip, fuse_multi)
+          double *sd = kk == 0 ? a.cheb.side_lo : a.cheb.side_hi;
+          if (sd && out) sd[3 * (j * NX + i) + c] = v;
+        }
+        emit(c, v);
+      }
     };
     if (odd_row) rest(std::true_type{}); else rest(std::false_type{});
   };
@@ -351,8 +358,8 @@ k_kron3_q2(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];                            // [2 buffers][9 fields][1024 nodes of the tile plane]
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;  // uniform over the grid: written by the previous launches only
   int col, zc; tile_of(a, col, zc);                        // workgroup-uniform: either tile shape, never both
-  if (col < a.n64 * a.nty64) kron_tile<64, false>(a, x, y, L, 60 * (col / a.nty64) - 2, col % a.nty64, zc);
-  else kron_tile<32, false>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
+  if (col < a.n64 * a.nty64) kron_tile<64, 0>(a, x, y, L, 60 * (col / a.nty64) - 2, col % a.nty64, zc);
+  else kron_tile<32, 0>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
 }
 // the same sweep with the Chebyshev (root form) update fused into the stores (polynomial preconditioner of the displacement CG: no vector kernels and no
 // reductions between the operator applications of one preconditioner call)
@@ -361,8 +368,17 @@ k_kron3_q2_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y
   extern __shared__ double L[];
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
   int col, zc; tile_of(a, col, zc);                        // workgroup-uniform: either tile shape, never both
-  if (col < a.n64 * a.nty64) kron_tile<64, true>(a, x, y, L, 60 * (col / a.nty64) - 2, col % a.nty64, zc);
-  else kron_tile<32, true>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
+  if (col < a.n64 * a.nty64) kron_tile<64, 1>(a, x, y, L, 60 * (col / a.nty64) - 2, col % a.nty64, zc);
+  else kron_tile<32, 1>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
+}
+// slab partitions: additionally the raw partial product on the two shared node planes (KronCheb::side_lo / side_hi)
+__global__ void __launch_bounds__(1024)
+k_kron3_q2_cheb_side(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ double L[];
+  if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
+  int col, zc; tile_of(a, col, zc);                        // workgroup-uniform: either tile shape, never both
+  if (col < a.n64 * a.nty64) kron_tile<64, 2>(a, x, y, L, 60 * (col / a.nty64) - 2, col % a.nty64, zc);
+  else kron_tile<32, 2>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
 }
 
 
@@ -371,7 +387,7 @@ k_kron3_q2_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y
 //   M (1, cM, 1), cM = 2(mL+mR);  K (-1, cK, -1), cK = mL+mR;  O (1, ., -1);  D = mL - mR.
 // Every node is a vertex node: 3-plane register window, one plane per barrier, halo of one node / row / plane.  Tiles: 64 lanes x 16
 // rows (62 x 14 valid) and 32 lanes x 32 rows (30 x 30 valid).
-template <int TXN, bool CHEB>
+template <int TXN, int CHEB>
 __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__restrict__ x, double *__restrict__ y, double *L, const int X0, const int tyi, const int zc) {
   constexpr int RPW = 64 / TXN, TYR = 16 * RPW, VY = TYR - 2;
   const int tid = threadIdx.x;
@@ -515,7 +531,11 @@ __device__ __forceinline__ void kron_tile_q1(const KronArgs &a, const double *__
       __syncthreads();
       if (!halo_wave) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) emit(c, xstage(XK[c], XM[c], XO[c], XD[c]));
+        for (int c = 0; c < 3; ++c) {
+          const double v = xstage(XK[c], XM[c], XO[c], XD[c]);
+          if constexpr (CHEB == 2) { double *sd = kk == 0 ? a.cheb.side_lo : a.cheb.side_hi; if (sd && out) sd[3 * (j * NX + i) + c] = v; }   // see kron_tile
+          emit(c, v);
+        }
       }
     }
     // rotate the window by one plane; the prefetched plane gets its Dirichlet columns zeroed as it enters
@@ -539,16 +559,24 @@ k_kron3_q1(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
   int col, zc; tile_of(a, col, zc);
-  if (col < a.n64 * a.nty64) kron_tile_q1<64, false>(a, x, y, L, 62 * (col / a.nty64) - 1, col % a.nty64, zc);
-  else kron_tile_q1<32, false>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
+  if (col < a.n64 * a.nty64) kron_tile_q1<64, 0>(a, x, y, L, 62 * (col / a.nty64) - 1, col % a.nty64, zc);
+  else kron_tile_q1<32, 0>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
 }
 __global__ void __launch_bounds__(1024)
 k_kron3_q1_cheb(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
   extern __shared__ double L[];
   if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
   int col, zc; tile_of(a, col, zc);
-  if (col < a.n64 * a.nty64) kron_tile_q1<64, true>(a, x, y, L, 62 * (col / a.nty64) - 1, col % a.nty64, zc);
-  else kron_tile_q1<32, true>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
+  if (col < a.n64 * a.nty64) kron_tile_q1<64, 1>(a, x, y, L, 62 * (col / a.nty64) - 1, col % a.nty64, zc);
+  else kron_tile_q1<32, 1>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
+}
+__global__ void __launch_bounds__(1024)
+k_kron3_q1_cheb_side(KronArgs a, const double *__restrict__ x, double *__restrict__ y) {
+  extern __shared__ double L[];
+  if (a.pcg && (a.pcg->done || a.pcg->finishing)) return;
+  int col, zc; tile_of(a, col, zc);
+  if (col < a.n64 * a.nty64) kron_tile_q1<64, 2>(a, x, y, L, 62 * (col / a.nty64) - 1, col % a.nty64, zc);
+  else kron_tile_q1<32, 2>(a, x, y, L, a.x0_32, col - a.n64 * a.nty64, zc);
 }
 
 // ---- 2D (Q2 and Q1): A_xx = (l+2G) Kx (x) My + G Mx (x) Ky,  A_yy = G Kx (x) My + (l+2G) Mx (x) Ky,
@@ -681,6 +709,8 @@ void kron_prepare_device() {
   PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q1, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2_cheb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q1_cheb, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q2_cheb_side, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  PORO_HIP(hipFuncSetAttribute((const void *)k_kron3_q1_cheb_side, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 }
 
 int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1, const PcgScalars *pcg,
@@ -749,8 +779,9 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   // ev0 / ev1 (optional): timestamps at the start / end of THIS dispatch, so the measured time is the kernel's own duration
   if (cheb) {
     a.cheb = *cheb;
-    if (ku == 2) hipExtLaunchKernelGGL(k_kron3_q2_cheb, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
-    else hipExtLaunchKernelGGL(k_kron3_q1_cheb, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
+    const bool side = cheb->side_lo || cheb->side_hi;
+    if (ku == 2) { if (side) hipExtLaunchKernelGGL(k_kron3_q2_cheb_side, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y); else hipExtLaunchKernelGGL(k_kron3_q2_cheb, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y); }
+    else { if (side) hipExtLaunchKernelGGL(k_kron3_q1_cheb_side, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y); else hipExtLaunchKernelGGL(k_kron3_q1_cheb, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y); }
   } else if (ku == 2) hipExtLaunchKernelGGL(k_kron3_q2, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
   else hipExtLaunchKernelGGL(k_kron3_q1, dim3((unsigned)nblk), dim3(1024), lds, s, ev0, ev1, 0, a, x, y);
   return (dot_partials && !fuse) ? -nblk : nblk;

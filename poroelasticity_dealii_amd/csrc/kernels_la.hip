@@ -415,6 +415,16 @@ template <int NC> __global__ void k_cheb_step(double *znew, const double *zj, co
   }
   if (gz_partials) { acc = block_sum(acc, sh); store_partial(gz_partials, acc); }
 }
+template <int NC> __global__ void k_cheb_fix_planes(double *znew, const double *zj, const double *g, const double *own_lo, const double *nbr_lo, const double *own_hi, const double *nbr_hi,
+                                                   DiagRef D, double omega, int64_t n, int64_t plane) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 2 * plane) return;
+  const bool hi = t >= plane; const int64_t k = hi ? t - plane : t;
+  const double *own = hi ? own_hi : own_lo, *nbr = hi ? nbr_hi : nbr_lo;
+  if (!own) return;
+  const int64_t i = hi ? n - plane + k : k;
+  znew[i] = fma(omega * diag_at<NC>(D, i), g[i] - (own[k] + nbr[k]), zj[i]);      // own + neighbour: the same two numbers on both ranks, and the sum commutes
+}
 template <class F> void dispatch_lanes(int L, F &&f) {
   switch (L) {
     case 2: f(std::integral_constant<int, 2>()); break;
@@ -566,6 +576,15 @@ void la_cheb_first(hipStream_t s, double *z, const double *g, const DiagVec &dv,
     case 2: hipLaunchKernelGGL(k_cheb_first<2>, grid_for(n), kBlock, 0, s, z, g, D, scale, n); break;
     case 3: hipLaunchKernelGGL(k_cheb_first<3>, grid_for(n), kBlock, 0, s, z, g, D, scale, n); break;
     default: hipLaunchKernelGGL(k_cheb_first<0>, grid_for(n), kBlock, 0, s, z, g, D, scale, n);
+  }
+}
+void la_cheb_fix_planes(hipStream_t s, double *znew, const double *zj, const double *g, const double *own_lo, const double *nbr_lo, const double *own_hi, const double *nbr_hi, const DiagVec &dv, double omega, int64_t n, int64_t plane) {
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, nullptr};
+  const unsigned grid = (unsigned)((2 * plane + kBlock - 1) / kBlock);
+  switch (diag_nc(dv, n)) {
+    case 2: hipLaunchKernelGGL(k_cheb_fix_planes<2>, grid, kBlock, 0, s, znew, zj, g, own_lo, nbr_lo, own_hi, nbr_hi, D, omega, n, plane); break;
+    case 3: hipLaunchKernelGGL(k_cheb_fix_planes<3>, grid, kBlock, 0, s, znew, zj, g, own_lo, nbr_lo, own_hi, nbr_hi, D, omega, n, plane); break;
+    default: hipLaunchKernelGGL(k_cheb_fix_planes<0>, grid, kBlock, 0, s, znew, zj, g, own_lo, nbr_lo, own_hi, nbr_hi, D, omega, n, plane);
   }
 }
 void la_cheb_step(hipStream_t s, double *znew, const double *zj, const double *g, const double *Az, const DiagVec &dv, double omega, int64_t n, int64_t n_owned, double *gz_partials) {
