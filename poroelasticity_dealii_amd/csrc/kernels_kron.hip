@@ -752,7 +752,12 @@ int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool 
   // (Q2 planes come in vertex / mid pairs), balanced to within one unit; chunks of fewer than 8 planes would be mostly halo
   a.zunit = ku == 2 ? 2 : 1;
   const int units = a.nn[2] / a.zunit;
-  const int upc = 8 / a.zunit;                                   // units in a chunk of 8 planes
+  static const int min_chunk_env = std::getenv("PORO_KRON_MIN_CHUNK") ? std::atoi(std::getenv("PORO_KRON_MIN_CHUNK")) : 0;
+  // shortest chunk: 8 planes (less is mostly halo) - unless the box is so thin (a slab of a partitioned run) that 8-plane chunks leave most CUs without a workgroup:
+  // then 4-plane chunks, which cost more loads per output but halve the length of the march every workgroup has to finish
+  int min_chunk = min_chunk_env > 0 ? min_chunk_env : 8;
+  if (min_chunk_env <= 0 && (int64_t)cols * ((units * a.zunit + 7) / 8) < n_cus) min_chunk = 4;       // (72 x 72 x 9 cells, one slab of 8: 23.0 -> 18.6 us per application; x 18: 27.3 -> 23.8)
+  const int upc = std::max(1, min_chunk / a.zunit);              // units in a shortest chunk
   int nzc = n_cus / cols; if (nzc > (units + upc - 1) / upc) nzc = (units + upc - 1) / upc; if (nzc < 1) nzc = 1;
   // 32-bit buffer offsets are relative to a chunk's first plane: a chunk (its planes + the halo + one prefetched pair) must span less than 2^31 bytes
   { const int64_t plane_bytes = (int64_t)a.nn[0] * a.nn[1] * 24, max_planes = (((int64_t)1 << 31) - 1) / plane_bytes - 2 * halo - 3;

@@ -6,7 +6,8 @@ from bench import material, BC_3D, bytes_per_apply
 
 def run(dim, n, deg, mode, reps=50):
     t0 = time.time()
-    P = pk.Problem.box(dim, [n] * dim, [10.0] * dim, deg, material(), BC_3D[:2 * dim])
+    cells = [n] * dim if isinstance(n, int) else list(n)
+    P = pk.Problem.box(dim, cells, [10.0 * c / cells[0] for c in cells], deg, material(), BC_3D[:2 * dim])
     t1 = time.time()
     G = pk.Context(P, 0, mode)
     t2 = time.time()
@@ -29,4 +30,4 @@ def run(dim, n, deg, mode, reps=50):
 if __name__ == "__main__":
     for spec in sys.argv[1:]:
         dim, n, deg, mode = spec.split(",")
-        run(int(dim), int(n), int(deg), pk.OP_MATRIX_FREE if mode == "mf" else pk.OP_CSR)
+        run(int(dim), int(n) if "x" not in n else [int(v) for v in n.split("x")], int(deg), pk.OP_MATRIX_FREE if mode == "mf" else pk.OP_CSR)     # n: cells per direction, or nx x ny x nz (a slab of a partitioned box)
