@@ -170,6 +170,7 @@ struct poro_ctx {
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
+  bool cheb_z1_ready = false;   // single-reduction PCG: the update kernel has already stored the first Chebyshev iterate of the coming preconditioner call
   int timing_stride = 1;   // events on every timing_stride-th launch of a family (poro_timers_enable)
   poro::DevBuf<double> cheb_side_lo, cheb_side_hi;   // partial products of the fused Chebyshev kernel on the shared planes (slab partitions)
   poro::DevBuf<poro::Cg1State> cg1_state; poro::DevBuf<double> cg1_z[2], cg1_w[2];   // single-reduction PCG of partitioned runs ([0]: displacement-sized, [1]: pressure-sized)
@@ -232,7 +233,7 @@ void pcg_first_direction(hipStream_t s, double *d, const double *g, const DiagVe
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red);
 void cg1_dots(hipStream_t s, const double *g, const double *z, const double *w, const double *b /*nullable: adds b.b*/, int64_t n_owned, double *partials /*4 sets*/);
 void cg1_scalars(hipStream_t s, Cg1State *st, const double *red, int first, double abs_tol, double rel_tol, int max_iter, int stop_rule);
-void cg1_update(hipStream_t s, const Cg1State *st, double *d, double *sv, double *x, double *g, const double *z, const double *w, const uint8_t *inert, int64_t n);
+void cg1_update(hipStream_t s, const Cg1State *st, double *d, double *sv, double *x, double *g, const double *z, const double *w, const DiagVec &dv /* inert mask; z1_out: also store z1_scale D^-1 g_new */, int64_t n);
 void pcg_scalars_start(hipStream_t s, PcgScalars *sc, const double *red /*bb, gg, gz*/, double abs_tol, double rel_tol, int max_iter, int stop_rule);
 // single-rank fast path: the consumers reduce the block partials themselves (no scalar kernels, no host round trip);
 // parity = iteration index & 1 selects the g.z slot read / written

@@ -339,6 +339,7 @@ int pcg_single_reduction(poro_ctx *c, const std::function<bool(const double *, d
   int batch = expect > 0 ? next_batch(0) : 1;
   while (true) {
     for (int k = 0; k < batch; ++k) {
+      c->cheb_z1_ready = precond && enq > 0 && diag.z1_out != nullptr;      // stored by the previous cg1_update
       if (precond) (void)(*precond)(g, z, nullptr);
       else if (jacobi) la_cheb_first(s, z, g, diag, 1.0, n);        // z = D^-1 g (zero on the inert dofs)
       else la_copy(s, z, g, n);
@@ -347,7 +348,7 @@ int pcg_single_reduction(poro_ctx *c, const std::function<bool(const double *, d
       pcg_scalars_sum(s, part, 4, red);
       allreduce_sum(c, red, 4);
       cg1_scalars(s, st, red, enq == 0 ? 1 : 0, opts->abs_tol, opts->rel_tol, opts->max_iter, opts->stop_rule);
-      cg1_update(s, st, d, sv, x, g, z, w, diag.inert, n);
+      cg1_update(s, st, d, sv, x, g, z, w, diag, n);
       ++enq;
     }
     PORO_HIP(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
@@ -1342,7 +1343,8 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         Timed tm(c, "precondition_u_chebyshev");
         hipStream_t s = c->stream;
         double *X[2] = {(m % 2 == 0) ? z : c->cheb_z.p, (m % 2 == 0) ? c->cheb_z.p : z};   // z_{j+1} lands in X[j & 1]; the last one (j = m) in z
-        if (!gz_partials) la_cheb_first(s, X[0], g, dj, 1.0 / roots[0], c->n_u);   // inside the iteration z_1 = D^-1 g / r_0 was stored by the residual update (DiagVec::z1_out)
+        if (!gz_partials && !c->cheb_z1_ready) la_cheb_first(s, X[0], g, dj, 1.0 / roots[0], c->n_u);   // inside the iteration z_1 = D^-1 g / r_0 was stored by the residual update (DiagVec::z1_out)
+        c->cheb_z1_ready = false;
         bool dot_done = false;
         // (the device-side "solve finished" flag may only gate launches inside the iteration: before pcg_scalars_start it still holds the previous solve's state)
         const PcgScalars *pstate = gz_partials ? c->scal.p : nullptr;

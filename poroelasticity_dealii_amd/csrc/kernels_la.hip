@@ -642,13 +642,16 @@ __global__ void k_cg1_scalars(Cg1State *st, const double *red, int first, double
   st->alpha = alpha; st->beta = beta; st->gamma_old = gamma; st->alpha_old = alpha; st->it += 1;
 }
 // d = -z + beta d, s = -w + beta s (= A d), x += alpha d, g += alpha s; inert (Dirichlet) dofs keep d = s = 0 whatever the operator left in w there
-__global__ void k_cg1_update(const Cg1State *st, double *d, double *sv, double *x, double *g, const double *__restrict__ z, const double *__restrict__ w, const uint8_t *inert, int64_t n) {
+template <int NC> __global__ void k_cg1_update(const Cg1State *st, double *d, double *sv, double *x, double *g, const double *z /* may be z1_out */, const double *__restrict__ w, const uint8_t *inert, int64_t n,
+                                              DiagRef D, double *z1_out, double z1_scale) {
   if (st->done) return;
   const double alpha = st->alpha, beta = st->beta;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    if (inert && inert[i]) continue;
+    if (inert && inert[i]) { if (z1_out) z1_out[i] = 0.0; continue; }
     const double di = fma(beta, d[i], -z[i]), si = fma(beta, sv[i], -w[i]);
-    d[i] = di; sv[i] = si; x[i] = fma(alpha, di, x[i]); g[i] = fma(alpha, si, g[i]);
+    const double gi = fma(alpha, si, g[i]);
+    d[i] = di; sv[i] = si; x[i] = fma(alpha, di, x[i]); g[i] = gi;
+    if (z1_out) z1_out[i] = z1_scale * diag_at<NC>(D, i) * gi;      // first iterate of the polynomial preconditioner of the NEXT iteration (DiagVec::z1_out), saves a kernel
   }
 }
 void cg1_dots(hipStream_t s, const double *g, const double *z, const double *w, const double *b, int64_t n_owned, double *partials) {
@@ -657,8 +660,13 @@ void cg1_dots(hipStream_t s, const double *g, const double *z, const double *w, 
 void cg1_scalars(hipStream_t s, Cg1State *st, const double *red, int first, double abs_tol, double rel_tol, int max_iter, int stop_rule) {
   hipLaunchKernelGGL(k_cg1_scalars, 1, 1, 0, s, st, red, first, abs_tol, rel_tol, max_iter, stop_rule);
 }
-void cg1_update(hipStream_t s, const Cg1State *st, double *d, double *sv, double *x, double *g, const double *z, const double *w, const uint8_t *inert, int64_t n) {
-  hipLaunchKernelGGL(k_cg1_update, grid_for(n), kBlock, 0, s, st, d, sv, x, g, z, w, inert, n);
+void cg1_update(hipStream_t s, const Cg1State *st, double *d, double *sv, double *x, double *g, const double *z, const double *w, const DiagVec &dv, int64_t n) {
+  const DiagRef D{dv.full, dv.cls, dv.tab, dv.ncomp, nullptr};
+  switch (dv.z1_out ? diag_nc(dv, n) : 0) {
+    case 2: hipLaunchKernelGGL(k_cg1_update<2>, grid_for(n), kBlock, 0, s, st, d, sv, x, g, z, w, dv.inert, n, D, dv.z1_out, dv.z1_scale); break;
+    case 3: hipLaunchKernelGGL(k_cg1_update<3>, grid_for(n), kBlock, 0, s, st, d, sv, x, g, z, w, dv.inert, n, D, dv.z1_out, dv.z1_scale); break;
+    default: hipLaunchKernelGGL(k_cg1_update<0>, grid_for(n), kBlock, 0, s, st, d, sv, x, g, z, w, dv.inert, n, D, dv.z1_out, dv.z1_scale);
+  }
 }
 void pcg_scalars_sum(hipStream_t s, const double *partials, int n_sets, double *red) {
   hipLaunchKernelGGL(k_scalars_sum, 1, kBlock, 0, s, (const PcgScalars *)nullptr, partials, n_sets, red);
