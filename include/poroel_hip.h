@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PORO_ABI_VERSION 3   /* 2: poro_solver_opts.omega, PORO_PREC_SSOR / FDM / ILU0, PORO_VEC_STRESS0; 3: poro_solver_opts.stop_rule, poro_constraints, PORO_PREC_FDM for the displacement system */
+#define PORO_ABI_VERSION 3   /* 2: poro_solver_opts.omega, PORO_PREC_SSOR / FDM / ILU0, PORO_VEC_STRESS0; 3: poro_solver_opts.stop_rule / poly_degree, poro_constraints, PORO_PREC_FDM and PORO_PREC_CHEBYSHEV for the displacement system, general form of poro_partition, prescribed pressures */
 
 /* Reference-cell tables: exactly the numbers the reference pulls out of
  * FEValues / FEFaceValues (PoroElasticDisplacementSolver.h:162-173,
