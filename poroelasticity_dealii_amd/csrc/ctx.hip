@@ -981,6 +981,7 @@ double estimate_lmax_u(poro_ctx *c, const std::function<bool(const double *, dou
   hipStream_t s = c->stream; const int64_t n = c->n_u, n_own = owned(c, n, c->comm.part.plane_u);
   std::vector<double> hv(n); for (int64_t i = 0; i < n; ++i) hv[i] = std::sin(0.731 * (double)i) + 0.3 * std::cos(0.013 * (double)i * (double)(i % 7));
   DevBuf<double> r, z, p, ap; r.upload(hv); z.alloc(n); p.alloc(n); ap.alloc(n);
+  exchange_add(c, r.p, n, c->comm.part.plane_u);                      // partitioned runs: the start vector was filled by LOCAL index - make the copies of the shared dofs agree (any consistent vector will do)
   la_mask_zero(s, r.p, dj.inert, n);
   la_cheb_first(s, z.p, r.p, dj, 1.0, n);                            // z = D^-1 r
   la_copy(s, p.p, z.p, n);

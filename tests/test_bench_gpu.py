@@ -74,3 +74,16 @@ def test_two_rank_rehearsal():
     its = w["cg_u"] + w["cg_p"] + w["cg_proj"]; solves = 1 + w["residual_p"] + 3
     assert fam["allreduce"] <= its + 2 * solves + w["residual_p"] + 8, (fam, w)
     assert fam["halo_exchange"] <= w["apply_u"] + w["apply_p"] + 2 * solves + 24, (fam, w)
+
+
+def test_partitioned_chebyshev_takes_the_single_rank_iteration_count():
+    """the polynomial's interval comes from a Lanczos estimate of lambda_max; on a partition its start vector must agree on the shared planes, otherwise the estimate
+    drifts with the number of ranks (it once hit the loose element bound at 4 ranks: 46 instead of 38 iterations at 72^3).  Same mesh on 1 and on 3 ranks: same count."""
+    base = [os.path.join(ROOT, "bench.py"), "--cells", "24", "--steps", "1", "--warmup", "1", "--no-variants", "--no-weak-line", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable] + base, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, (r1.stdout + r1.stderr)[-2000:]
+    r3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + base + ["--gpus", "3", "--share-gpu"],
+                        capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0, (r3.stdout + r3.stderr)[-2000:]
+    i1, i3 = _line(r1.stdout)["cg_iterations_u"][0][0], _line(r3.stdout)["cg_iterations_u"][0][0]
+    assert abs(i1 - i3) <= 1, (i1, i3)
