@@ -136,6 +136,12 @@ void timers_collect(poro_ctx *c) {
     kv.second.pending.clear();
   }
 }
+// before a dispatch that carries start / stop events in a stream whose other dispatches carry none: a marker that drains the stream, so that the bracket holds the kernel
+// alone (otherwise its first workgroups share the chip with the tail of the previous kernel and the bracket reads a few microseconds long)
+void isolate_sampled_dispatch(poro_ctx *c) {
+  if (c->timing_stride <= 1) return;
+  hipEvent_t m = event_get(c); (void)hipEventRecord(m, c->stream); c->event_pool.push_back(m);
+}
 // a start / stop event pair that is returned to the context's pool on every exit path
 struct EventPair {
   poro_ctx *c; hipEvent_t e0, e1;
@@ -291,6 +297,7 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
   if (mode == PORO_OP_MATRIX_FREE && c->box.enabled && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
     int slots;
     if (c->timing && c->timers["apply_u_matrix_free"].sample(c->timing_stride)) {   // events attached to the dispatch itself: the kernel's own duration, without the gaps to its neighbours in the stream
+      isolate_sampled_dispatch(c);
       Timer &t = c->timers["apply_u_matrix_free"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
       slots = kron_apply(c->stream, mf_args(c), x, y, true, c->n_cus, dot_partials, e0, e1, pcg_state);
       t.pending.emplace_back(e0, e1); t.launches++;
@@ -1357,7 +1364,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
             const poro_partition &pt = c->comm.part; const int64_t plane = pt.plane_u;
             KronCheb kc; kc.g = g; kc.znew = zn; kc.omega = omega; kc.cls = c->diag_u_cls.p; kc.tab = c->diag_u_tab.p;
             kc.side_lo = pt.has_lower ? c->cheb_side_lo.p : nullptr; kc.side_hi = pt.has_upper ? c->cheb_side_hi.p : nullptr;
-            if (c->timing && c->timers["apply_u_chebyshev_fused"].sample(c->timing_stride)) { Timer &t = c->timers["apply_u_chebyshev_fused"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
+            if (c->timing && c->timers["apply_u_chebyshev_fused"].sample(c->timing_stride)) { isolate_sampled_dispatch(c); Timer &t = c->timers["apply_u_chebyshev_fused"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
                                                                                            (void)kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, nullptr, e0, e1, nullptr, &kc); t.pending.emplace_back(e0, e1); t.launches++; }
             else (void)kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, nullptr, nullptr, nullptr, nullptr, &kc);
             if (pt.has_lower || pt.has_upper) {
@@ -1370,7 +1377,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
             double *dp = (last && gz_partials) ? gz_partials : nullptr;
             if (dp) PORO_HIP(hipMemsetAsync(dp, 0, kMaxPartials * sizeof(double), s));
             int slots;
-            if (c->timing && c->timers["apply_u_chebyshev_fused"].sample(c->timing_stride)) { Timer &t = c->timers["apply_u_chebyshev_fused"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
+            if (c->timing && c->timers["apply_u_chebyshev_fused"].sample(c->timing_stride)) { isolate_sampled_dispatch(c); Timer &t = c->timers["apply_u_chebyshev_fused"]; hipEvent_t e0 = event_get(c), e1 = event_get(c);
                              slots = kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, dp, e0, e1, pstate, &kc); t.pending.emplace_back(e0, e1); t.launches++; }
             else slots = kron_apply(s, mf_args(c), zj, nullptr, true, c->n_cus, dp, nullptr, nullptr, pstate, &kc);
             if (dp && slots > 0) dot_done = true;
