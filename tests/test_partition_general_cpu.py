@@ -91,3 +91,40 @@ def test_partition_bookkeeping():
         for P in pieces:
             P.close()
         PG.close()
+
+
+def test_partition_refusals():
+    """what the provider does not partition says so: hanging-node meshes, prescribed pressures, more ranks than cells, bad rank numbers"""
+    from common import BC_2D, box_problem, material
+    P = pk.Problem.refined_box(2, [4, 4], [10.0, 10.0], 2, material(), BC_2D, [1, 1], [3, 3])
+    with pytest.raises(RuntimeError, match="hanging-node"):
+        P.partition(0, 2)
+    P.close()
+    P = box_problem(2, 3, 1); P.set_pressure_bc([(1, 0.0)])
+    with pytest.raises(RuntimeError, match="prescribed pressures"):
+        P.partition(0, 2)
+    P.close()
+    P = box_problem(2, (2, 1), 1)
+    with pytest.raises(RuntimeError, match="fewer cells than ranks"):
+        P.partition(0, 3)
+    with pytest.raises(RuntimeError, match="bad rank"):
+        P.partition(2, 2)
+    one = P.partition(0, 1)                       # a single piece is the whole mesh, renumbered, without neighbours
+    assert one.desc.part.n_neighbours == 0 and one.desc.n_dofs_u == P.desc.n_dofs_u and sorted(one.local_to_global_u) == list(range(P.desc.n_dofs_u))
+    one.close(); P.close()
+
+
+def test_rigid_plate_ties_are_ordinary_constraint_entries():
+    from common import box_problem
+    P = box_problem(2, (3, 2), 2, bc=[(0, 0, 0.0), (2, 1, 0.0)])
+    n_before = P.desc.cons_u.n
+    P.tie_boundary([(3, 1)])
+    c = P.desc.cons_u
+    top = 2 * 3 + 1                                # nodes on the top boundary of a 3-cell-wide Q2 box
+    assert n_before == 0 and c.n == top - 1 and not P.desc.box.enabled        # all but the master; constraint lists run on the general operators
+    masters = {c.master[c.ptr[i]] for i in range(c.n)}
+    assert len(masters) == 1 and all(c.ptr[i + 1] - c.ptr[i] == 1 and c.weight[c.ptr[i]] == 1.0 and c.inhomogeneity[i] == 0.0 for i in range(c.n))
+    assert all(c.dof[i] % 2 == 1 for i in range(c.n))                          # the y components
+    with pytest.raises(RuntimeError, match="already applied"):
+        P.tie_boundary([(3, 1)])
+    P.close()
