@@ -339,6 +339,7 @@ int pcg_single_reduction(poro_ctx *c, const std::function<bool(const double *, d
   apply(x, w, nullptr);
   pcg_init_residual(s, g, w, b, diag.inert, n);        // g = A x - b, zero on the inert dofs
   la_fill(s, d, 0.0, n); la_fill(s, sv, 0.0, n);
+  DiagVec upd = diag; if (jacobi && !precond) { upd.z1_out = z; upd.z1_scale = 1.0; }   // Jacobi: the update kernel also leaves z = D^-1 g_new for the next iteration (in place of z)
   Cg1State hs{};
   int expect = 0, enq = 0;
   if (its_hint && its_hint[0] > 0) { expect = its_hint[1] > 0 ? 2 * its_hint[0] - its_hint[1] : its_hint[0]; expect = std::min(std::max(expect, its_hint[0] / 2), its_hint[0]); }   // (never above the last count: nothing here is gated)
@@ -348,14 +349,14 @@ int pcg_single_reduction(poro_ctx *c, const std::function<bool(const double *, d
     for (int k = 0; k < batch; ++k) {
       c->cheb_z1_ready = precond && enq > 0 && diag.z1_out != nullptr;      // stored by the previous cg1_update
       if (precond) (void)(*precond)(g, z, nullptr);
-      else if (jacobi) la_cheb_first(s, z, g, diag, 1.0, n);        // z = D^-1 g (zero on the inert dofs)
+      else if (jacobi) { if (enq == 0) la_cheb_first(s, z, g, diag, 1.0, n); }   // z = D^-1 g (zero on the inert dofs); after the first iteration the update kernel stores it with the new residual
       else la_copy(s, z, g, n);
       apply(z, w, nullptr);
       cg1_dots(s, g, z, w, enq == 0 ? b : nullptr, n_own, part);
       pcg_scalars_sum(s, part, 4, red);
       allreduce_sum(c, red, 4);
       cg1_scalars(s, st, red, enq == 0 ? 1 : 0, opts->abs_tol, opts->rel_tol, opts->max_iter, opts->stop_rule);
-      cg1_update(s, st, d, sv, x, g, z, w, diag, n);
+      cg1_update(s, st, d, sv, x, g, z, w, upd, n);
       ++enq;
     }
     PORO_HIP(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
