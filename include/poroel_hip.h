@@ -187,12 +187,13 @@ enum { PORO_STOP_RHS = 0, PORO_STOP_REDUCTION = 1 };
  * For the displacement system PORO_PREC_FDM is the BLOCK fast diagonalisation: the diagonal blocks A_cc of the elasticity operator (one per
  * displacement component) are Kronecker sums of 1D FE_Q(k) matrices whenever every Dirichlet condition covers whole faces, and are inverted
  * exactly the same way (per-component 1D eigenvectors, fp64 MFMA transforms); CG on a 10 M-dof box then takes ~20 iterations instead of ~250.
- * PORO_PREC_ILU0 = incomplete LU on the pattern of the assembled CSR matrix (factorised on the host once per matrix, level-scheduled
- * triangular solves on the device; one rank, moderate sizes).
+ * PORO_PREC_ILU0 = incomplete LU on the pattern of the assembled CSR matrix (factorised once per matrix ON THE DEVICE, level-scheduled in the natural
+ * row order like the triangular solves, so the factors equal those of a sequential IKJ sweep; one rank, moderate sizes).
  * PORO_PREC_CHEBYSHEV (displacement system) = Chebyshev polynomial in D^-1 A of degree poly_degree around the Jacobi preconditioner: the CG iteration
  * count drops by about the degree + 1 while the operator applications of the polynomial need no dot products and, on 3D boxes, no vector kernels either
  * (the update z_{j+1} = z_j + D^-1 (g - A z_j) / r_j - roots r_j of the shifted Chebyshev polynomial - is applied inside the structured operator kernel where the product leaves the registers): fewer bytes and far fewer reductions per
- * operator application than Jacobi-CG.  lambda_max(D^-1 A) is estimated by a power iteration when the matrix is (re)built. */
+ * operator application than Jacobi-CG.  lambda_max(D^-1 A) comes from the Lanczos tridiagonal of 25 Jacobi-CG steps when the matrix is (re)built (+5 %,
+ * capped on uniform boxes by the rigorous element bound lambda_max(diag(K_e)^-1 K_e)). */
 enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3, PORO_PREC_ILU0 = 4, PORO_PREC_CHEBYSHEV = 5 };
 enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };
 enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_JACOBIAN_P = 3 };

@@ -356,8 +356,9 @@ k_proj_rhs(AsmArgs a, const int32_t *__restrict__ cells, const double *__restric
 template <int DIM, int NT> static void launch_asm_u_nt(hipStream_t s, const AsmArgs &a, unsigned grid, const int32_t *cells, int32_t cell, int mode, const int64_t *rp, const int32_t *col,
                                                        double *val, double *lift, double *Ke, int interleaved) {
   const size_t lds = AsmSmem::bytes(DIM, a.ns_u, a.fe.nq_u, a.nv);
-  static bool attr_set = false;   // Q2 hexes need 73 KB of LDS per workgroup: above the 64 KB default of dynamic LDS
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_asm_u_matrix<DIM, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  // Q2 hexes need 73 KB of LDS per workgroup: above the 64 KB default of dynamic LDS.  Function attributes are per device: one flag per device index
+  static bool attr_set[64] = {false}; int dev = 0; (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_asm_u_matrix<DIM, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (dev >= 0 && dev < 64) attr_set[dev] = true; }
   hipLaunchKernelGGL((k_asm_u_matrix<DIM, NT>), grid, NT, lds, s, a, cells, cell, mode, rp, col, val, lift, Ke, interleaved);
 }
 template <int DIM> static void launch_asm_u(hipStream_t s, const AsmArgs &a, unsigned grid, const int32_t *cells, int32_t cell, int mode, const int64_t *rp, const int32_t *col, double *val,

@@ -715,7 +715,7 @@ void kron_prepare_device() {
 
 int kron_apply(hipStream_t s, const MfArgs &m, const double *x, double *y, bool constrained, int n_cus, double *dot_partials, hipEvent_t ev0, hipEvent_t ev1, const PcgScalars *pcg,
                const KronCheb *cheb) {
-  static bool checked = false;
+  static bool checked = false;   // a host-side arithmetic check of the integer 1D matrices (no device state involved: once per process is right for any number of devices)
   if (!checked) { check_q2_element_matrices(); checked = true; }
   KronArgs a{};
   const int ku = m.k_u;
