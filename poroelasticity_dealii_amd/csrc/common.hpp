@@ -83,6 +83,22 @@ struct FdmU { int dim = 0; int nn[3] = {1, 1, 1}; double coef[3][3] = {}; FdmuDi
               // slab-partitioned form: node planes of the last direction are gathered per column group by an all-to-all (as FdmDist for the Q1 systems)
               bool dist = false; int n_ranks = 1, rank = 0; std::vector<int> layers, off /* first global node plane of every rank */; int ng = 0; int64_t ncol_total = 0, C = 0;
               int max_own = 0, max_nl = 0; DevBuf<double> sendbuf, recvbuf, tz1, tz2; };
+// octant form of the block fast diagonalisation (kernels_fdmo.hip; 3D boxes, one rank, every direction mirror-symmetric for every component).
+// The even / odd butterflies of the three directions commute with everything inside the preconditioner, so they are hoisted out of it: the CG residual g and
+// the preconditioned residual z live as 8 octants per component, Q[c][o][kz][ky][kx] with o = 4 pz + 2 py + px (p = 0: even part e_k = v_k + v_k', 1: odd
+// part o_k = v_k - v_k' of the pair k < h, k' = n - 1 - k; the centre node of an odd line is its own mirror: e = v, o = 0), h = (n + 1) / 2 entries per
+// direction.  Each of the 24 (component, octant) blocks is then an independent half-size 3D transform, done in three passes (x y fused per plane, z
+// forward + eigenvalue scaling + z backward, y x fused per plane); the butterflies ride in the CG update kernels, which touch every entry anyway.
+struct FdmOct {
+  bool built = false; int nt = 0;                 // 16-wide MFMA tiles per half line (max over the directions), 1..5
+  int n[3] = {1, 1, 1}, h[3] = {1, 1, 1}; int hxp = 2;   // hxp: row pitch = h[0] rounded up to even (16-byte aligned rows; the pad entry is zero and stays zero)
+  int64_t co_stride = 0, n_oct = 0;               // entries per (component, octant) = hxp h[1] h[2]; 24 co_stride
+  double coef[3][3] = {};
+  DevBuf<double> fwd[3][3][2], bwd[3][3][2], lam[3][3][2];   // [component][direction][parity]: half-size transforms in MFMA fragment order [tile][4 nt][64], eigenvalues (inf = no such mode)
+  DevBuf<double> g, z, t;                         // residual, preconditioned residual, scratch - all in octant form
+  std::vector<double> h_lam[3][3][2];             // host copies of the eigenvalues
+  DevBuf<double> bxy;                             // [component][py][px][my][mx] = coef_x lam_x[mx] + coef_y lam_y[my]: the part of the eigenvalue sum a z line shares (pass 2 reads it per column)
+};
 // dependency levels of the lower / upper triangle in natural row order (rows of one level can be swept concurrently)
 struct SsorLevels { DevBuf<int32_t> fwd_rows, bwd_rows; std::vector<int64_t> fwd_off, bwd_off; bool built = false; };
 struct CsrDev {
@@ -165,8 +181,10 @@ struct poro_ctx {
   poro::DevBuf<double> ilu_u, ilu_J, ilu_M; bool ilu_u_valid = false, ilu_J_valid = false, ilu_M_valid = false;   // ILU(0) factors on the CSR patterns
   poro::DevBuf<double> wz_p;   // z = P^-1 g of an explicit preconditioner (pressure-sized systems)
   poro::FdmScalar fdm_p; poro::FdmDist fdm_dist; poro::DevBuf<double> fdm_t1, fdm_t2;   // fast diagonalisation of the Q1 box operators
-  double cheb_lmax = 0;   // estimate of lambda_max(D^-1 A_u) (power iteration at matrix build; 0 = not yet computed)
+  double cheb_lmax = 0;   // estimate of lambda_max(D^-1 A_u) (Lanczos at matrix build; 0 = not yet computed)
+  double cheb_ratio_default = 0;   // default interval ratio of the Chebyshev preconditioner, from the GLOBAL mesh size (0 = not yet computed)
   poro::DevBuf<double> cheb_z, cheb_t;
+  poro::FdmOct fdm_oct;
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
@@ -295,6 +313,20 @@ void fdmu_apply(hipStream_t s, const FdmU &F, const double *g, double *z, void *
 void fdmu_window(hipStream_t s, double *dst, const double *src, bool to_block, int ncomp, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid,
                  int64_t grid_stride, int64_t grid_planes, int64_t grid_col0, int64_t grid_plane0);
 void fdmu_lines(hipStream_t s, const FdmU &F, const FdmuDir *last_dir, int64_t C, int64_t col0, int64_t ncol_valid, void *in, void *out);
+// ---- kernels_fdmo.hip: octant form (see FdmOct) --------------------------------------------------
+bool fdmo_usable(int dim, const int nn[3]);          // 3D, half lines of at most 80 entries
+void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s);   // sizes + buffers
+// half-size transforms of (component, direction) from the generalised eigenvectors S (nn x nn row-major, every mode symmetric or antisymmetric) and eigenvalues lam
+bool fdmo_upload_dir(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn);
+void fdmo_finalize(FdmOct &O);   // after every (component, direction) has been uploaded: derived tables
+void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch_oct);   // z = blockdiag(A_cc)^-1 g, all in octant form
+void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v_nodal, double *q_oct);   // q = H v (node-interleaved vector -> octant form)
+void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r_oct, double *v_nodal);     // v = H^-1-form of the backward transform: v_k = a + b, v_k' = a - b
+// the vector kernels of pcg() with g / z in octant form (same device-side scalar protocol as their nodal counterparts in kernels_la.hip)
+void fdmo_init_residual(hipStream_t s, const FdmOct &O, double *g_oct, const double *Ax, const double *b, const uint8_t *inert);
+void fdmo_first_direction(hipStream_t s, const FdmOct &O, double *d, const double *g_oct, const double *z_oct, double *partials /*2 sets: gg, gz*/);
+void fdmo_update_g(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, double *g_oct, const double *h, const uint8_t *inert, const double *partials_dh, double *partials_out /*gg*/);
+void fdmo_update_d(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, int it, double *x, double *d, const double *z_oct, const double *partials_in /*2 sets*/);
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
 int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                const PcgScalars *pcg = nullptr /* launch becomes a no-op once pcg->done / finishing is set */,

@@ -380,12 +380,14 @@ int pcg_single_reduction(poro_ctx *c, const std::function<bool(const double *, d
 // when it has already left the block partials of g . z (over the owned rows) in gz_partials.
 int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *)> &apply, int64_t n, int64_t plane, double *x, const double *b,
         const DiagVec &diag, double *g, double *d, double *h, const poro_solver_opts *opts, poro_solve_info *info,
-        const std::function<bool(const double *, double *, double *)> *precond = nullptr, int *its_hint = nullptr, bool precond_gated = false) {
+        const std::function<bool(const double *, double *, double *)> *precond = nullptr, int *its_hint = nullptr, bool precond_gated = false,
+        const FdmOct *oct = nullptr /* single rank, explicit preconditioner: the residual and z = P^-1 g live in octant form (kernels_fdmo.hip), `g` is unused */) {
   static const bool two_reductions = std::getenv("PORO_TWO_REDUCTION_CG") != nullptr;    // A/B hook: the three-kernel recurrence on partitioned runs too
   if (c->comm.multi() && !two_reductions) return pcg_single_reduction(c, apply, n, plane, x, b, diag, g, d, h, opts, info, precond, its_hint);
   hipStream_t s = c->stream;
   const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
   double *zbuf = const_cast<double *>(diag.z);
+  if (oct) { if (!precond || c->comm.multi()) throw Error("pcg: the octant form needs an explicit preconditioner on one rank"); g = oct->g.p; zbuf = oct->z.p; }
   if (precond && !zbuf) throw Error("pcg: explicit preconditioner without a z vector");
   const int64_t n_own = owned(c, n, plane);
   const bool multi = c->comm.multi();
@@ -395,10 +397,10 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   int64_t applies = 0;
   // g = A x - b ; d = -P^-1 g ; gh = g.P^-1 g
   apply(x, h, nullptr); ++applies;
-  pcg_init_residual(s, g, h, b, diag.inert, n);
+  if (oct) fdmo_init_residual(s, *oct, g, h, b, diag.inert); else pcg_init_residual(s, g, h, b, diag.inert, n);
   la_dot_partials(s, b, b, n_own, part);
   if (precond) (void)(*precond)(g, zbuf, nullptr);
-  pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
+  if (oct) fdmo_first_direction(s, *oct, d, g, zbuf, part + kMaxPartials); else pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
   pcg_scalars_sum(s, part, 3, red);
   allreduce_sum(c, red, 3);
   pcg_scalars_start(s, sc, red, opts->abs_tol, opts->rel_tol, opts->max_iter, opts->stop_rule);
@@ -424,10 +426,12 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
       if (!apply(d, h, part_dh)) pcg_dot_dh(s, sc, d, h, n_own, part_dh);
       ++applies;
       if (multi) { pcg_scalars_sum(s, part_dh, 1, red); allreduce_sum(c, red, 1); }
-      pcg_update_g_fused(s, sc, (it - 1) & 1, g, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
-      if (precond && !(*precond)(g, zbuf, part + kMaxPartials)) la_dot_partials(s, g, zbuf, n_own, part + kMaxPartials);
+      if (oct) fdmo_update_g(s, *oct, sc, (it - 1) & 1, g, h, diag.inert, part_dh, part);
+      else pcg_update_g_fused(s, sc, (it - 1) & 1, g, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
+      if (precond && !(*precond)(g, zbuf, part + kMaxPartials)) la_dot_partials(s, g, zbuf, oct ? oct->n_oct : n_own, part + kMaxPartials);
       if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
-      pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
+      if (oct) fdmo_update_d(s, *oct, sc, (it - 1) & 1, it, x, d, zbuf, part);
+      else pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
     PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
     if (hs.done || hs.finishing) break;
@@ -734,6 +738,11 @@ void build_fdm_u(poro_ctx *c) {
     F.sendbuf.alloc(blk * N); F.recvbuf.alloc(blk * N); F.tz1.alloc((size_t)dim * F.ng * F.C); F.tz2.alloc((size_t)dim * F.ng * F.C);
     F.sendbuf.zero(c->stream); F.recvbuf.zero(c->stream); F.tz1.zero(c->stream); F.tz2.zero(c->stream);
   }
+  // octant form (kernels_fdmo.hip): one rank, 3D, every direction mirror-symmetric for every component, half lines of at most 80 entries
+  bool oct_ok = !multi && !F.single && !std::getenv("PORO_FDMU_NO_OCT");
+  { int nn3[3] = {F.nn[0], F.nn[1], F.nn[2]}; oct_ok = oct_ok && fdmo_usable(dim, nn3);
+    for (int d = 0; d < dim && oct_ok; ++d) for (int comp = 0; comp < dim; ++comp) oct_ok = oct_ok && F.fix[comp][d][0] == F.fix[comp][d][1];
+    if (oct_ok) fdmo_init(c->fdm_oct, nn3, F.coef, c->stream); }
   // eigenpairs per (direction, end conditions); components with the same end conditions share the host work.  A direction takes the even / odd
   // form (half the MFMA work) when every component has the same condition at both ends there - all components of a pass share one kernel
   for (int d = 0; d < dim; ++d) {
@@ -750,6 +759,7 @@ void build_fdm_u(poro_ctx *c) {
         FdmuDir &D = global_dir ? F.last_global[comp] : F.dir[comp][d];
         fdmu_upload_dir(D, S[key], lam[key], nnode, global_dir ? false : F.single, allow_split);
         all_split = all_split && D.split;
+        if (oct_ok && attempt == 0) oct_ok = fdmo_upload_dir(c->fdm_oct, comp, d, S[key], lam[key], nnode);
       }
       if (!allow_split || all_split) break;
       allow_split = false;                       // the numerical symmetry check failed for some component: the whole direction in the full form
@@ -757,6 +767,8 @@ void build_fdm_u(poro_ctx *c) {
   }
   c->fdmu_t1.alloc(c->n_u); c->fdmu_t2.alloc(c->n_u); c->fdmu_t1.zero(c->stream); c->fdmu_t2.zero(c->stream);   // (only finite values ever live in the scratch arrays)
   if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
+  if (oct_ok) fdmo_finalize(c->fdm_oct);
+  c->fdm_oct.built = oct_ok;
   F.built = true;
 }
 void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk);
@@ -1326,10 +1338,24 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
           PORO_HIP(hipMemcpyAsync(ke.data(), c->Ke.p, ke.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
           c->cheb_lmax = std::min(jacobi_scaled_lambda_max(c->dpc_u, ke), estimate_lmax_u(c, apply, dj));   // the element bound is rigorous but loose
         } else c->cheb_lmax = estimate_lmax_u(c, apply, dj); if (std::getenv("PORO_CHEB_VERBOSE")) std::fprintf(stderr, "[poro] lambda_max(D^-1 A_u) ~ %.6f\n", c->cheb_lmax); }
+      // `omega` doubles as the interval ratio; anything below 4 (the SSOR relaxation 1.2 a caller may have left there, 0) means "default"
       double ratio = opts->omega;
-      if (!(ratio > 1.0)) {   // default: a few times lambda_min, which scales with h^2 (calibrated on box runs of 8^3 .. 72^3 cells)
-        int nmax = 1; for (int k = 0; k < c->dim; ++k) nmax = std::max(nmax, c->box.enabled ? c->box.n[k] : (int)std::lround(std::pow((double)c->n_cells, 1.0 / c->dim)));
-        ratio = std::min(400.0, std::max(10.0, (c->k_u == 2 ? 0.2 : 0.05) * nmax * nmax));
+      if (!(ratio >= 4.0)) {   // default: a few times lambda_min, which scales with h^2 (calibrated on box runs of 8^3 .. 72^3 cells)
+        if (!(c->cheb_ratio_default > 0)) {
+          // from GLOBAL mesh sizes, so that every rank of a partitioned run builds the same polynomial (rank-local sizes gave uneven slabs different roots on
+          // either side of a shared plane): the cell layers of the partitioned direction (slabs) / the cell count (general partitions) are summed over the ranks
+          double h[2] = {(double)c->box.n[c->dim - 1], (double)c->n_cells};
+          if (c->comm.multi()) {
+            PORO_HIP(hipMemcpyAsync(c->red.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+            allreduce_sum(c, c->red.p, 2);
+            PORO_HIP(hipMemcpyAsync(h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
+          }
+          double nmax = 1;
+          if (c->box.enabled) { for (int k = 0; k < c->dim; ++k) nmax = std::max(nmax, k == c->dim - 1 ? h[0] : (double)c->box.n[k]); }
+          else nmax = std::round(std::pow(h[1], 1.0 / c->dim));
+          c->cheb_ratio_default = std::min(400.0, std::max(10.0, (c->k_u == 2 ? 0.2 : 0.05) * nmax * nmax));
+        }
+        ratio = c->cheb_ratio_default;
       }
       // root form: the residual polynomial of degree m + 1 is prod_i (1 - lambda / r_i) with the roots r_i of the Chebyshev polynomial shifted to
       // [lambda_max / ratio, lambda_max]; z_1 = D^-1 g / r_0, z_{j+1} = z_j + D^-1 (g - A z_j) / r_j.  Same polynomial as the three-term recurrence
@@ -1406,9 +1432,13 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     if (opts->preconditioner == PORO_PREC_FDM) {
       // z = blockdiag(A_cc)^-1 g by fast diagonalisation: the same device-controlled SolverCG recurrence with an explicit preconditioner vector
       build_fdm_u(c);
-      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { fdm_precondition_u(c, g, z); return false; };
+      const FdmOct *oct = c->fdm_oct.built ? &c->fdm_oct : nullptr;
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) {
+        if (oct) { Timed tm(c, "precondition_u_fdm"); fdmo_apply(c->stream, *oct, g, z, c->fdm_oct.t.p); }   // g, z in octant form: three contiguous sweeps
+        else fdm_precondition_u(c, g, z);
+        return false; };
       DiagVec dz; dz.full = c->dinv_u.p; dz.ncomp = c->dim; dz.inert = c->dir_mask.p; dz.z = c->wz_u.p;
-      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_fdm_u);
+      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_fdm_u, false, oct);
       la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
       PORO_HIP(hipStreamSynchronize(c->stream));
       return rc;
@@ -1637,10 +1667,15 @@ int poro_apply_preconditioner_u(poro_ctx *c, int32_t preconditioner, const doubl
     DevBuf<double> g, z; g.upload(g_host, c->n_u); z.alloc(c->n_u); z.zero(s);
     if (preconditioner == PORO_PREC_FDM) {
       build_fdm_u(c);
-      fdm_precondition_u(c, g.p, z.p);
+      FdmOct &O = c->fdm_oct;
+      // octant form where the solver uses it: butterflies outside (H, H'), the three transform passes in between - the timed part, as inside PCG
+      auto once = [&]() { if (O.built) fdmo_apply(s, O, O.g.p, O.z.p, O.t.p); else fdm_precondition_u(c, g.p, z.p); };
+      if (O.built) fdmo_from_nodal(s, O, g.p, O.g.p);
+      once();
+      if (O.built) fdmo_to_nodal(s, O, O.z.p, z.p);
       if (reps > 0 && seconds_per_apply) {
         EventPair ev(c); PORO_HIP(hipEventRecord(ev.e0, s));
-        for (int k = 0; k < reps; ++k) fdm_precondition_u(c, g.p, z.p);
+        for (int k = 0; k < reps; ++k) once();
         PORO_HIP(hipEventRecord(ev.e1, s)); PORO_HIP(hipEventSynchronize(ev.e1));
         float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1)); *seconds_per_apply = ms * 1e-3 / reps;
       }

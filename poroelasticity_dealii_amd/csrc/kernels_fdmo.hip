@@ -1,0 +1,513 @@
+// Octant form of the block fast-diagonalisation preconditioner of the displacement system (K-prec; the preconditioner slot of
+// PoroElasticDisplacementSolver<dim>::solve, PoroElasticDisplacementSolver.h:302-305) on 3D uniform boxes, one rank (gfx950, wave64, fp64 MFMA).
+//
+// kernels_fdmu.hip exploits that on a mirror-symmetric line every generalised eigenvector of the 1D FE_Q(k) pencil is even or odd: with
+// e_k = v_k + v_k', o_k = v_k - v_k' (k < h = (n + 1) / 2, k' = n - 1 - k; the centre node of an odd line is its own mirror: e = v, o = 0) a 1D
+// transform splits into two half-size products.  There the butterflies run inside every transform pass, and the passes still read / write the
+// node-interleaved CG vectors (24-byte strides: 2.4 x the useful HBM traffic in the x passes, profiles/r03_fdmu_baseline_counters.txt).  Here the
+// butterflies of all three directions are hoisted OUT of the preconditioner: they commute with the 1D transforms of the other directions, so
+//     z = H' (sum over the 8 parity octants of independent half-size 3D fast diagonalisations) H g,
+// with H the 8-point butterfly.  The CG residual g and z = P^-1 g therefore LIVE in octant form Q[c][o][kz][ky][kx] (o = 4 pz + 2 py + px), and H / H'
+// ride in the CG update kernels, which touch every entry anyway (g += alpha A d reads the eight mirror images of A d; d = -z + beta d scatters to them;
+// g.z = sum Q_g Q_z and |g|^2 = weighted sum Q_g^2 hold in octant form directly).  What is left of the preconditioner is 24 independent
+// (component, octant) blocks of h^3 entries, each a plain 3D tensor transform in contiguous planar storage:
+//     pass 1  (x, y fused per z-plane)    X[ky][kx] -> Fy X Fx^T
+//     pass 2  (z; per 16 NT columns)      X[kz][col] -> Bz diag(1 / (kx lam_x + ky lam_y + kz lam_z)) Fz X        (in place)
+//     pass 3  (y, x fused per z-plane)    X[my][mx] -> By X Bx^T
+// = 3 sweeps over the vector instead of 5, every access contiguous.  All three passes are ONE kernel: a block of <= 80 x 80 doubles is staged
+// in LDS, two chained GEMMs on v_mfma_f64_16x16x4_f64 with the data passing through LDS between them (in the bank-conflict-free layout the second
+// GEMM's operand reads need), the half-size transform matrices as the other operand straight from L2 in MFMA fragment order (each wave only needs
+// the 16 rows of its own output tile).  "contract columns": Y = X T^T, wave w owns output column tile w, data = A operand; "contract rows":
+// Y = T X, wave s owns output row tile s, data = B operand; either way the accumulator of tile (T, W) holds element (16 T + 4 q + kq, 16 W + j) in
+// register q of lane j + 16 kq, so one store routine serves both.
+#include "common.hpp"
+#include "device_reduce.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+#include <type_traits>
+
+namespace poro {
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct OctDims { int nx, ny, nz, hx, hy, hz, hxp; int64_t co; };   // nodes and half lengths per direction; hxp = row pitch (hx rounded up to even: 16-byte aligned rows, the pad entry stays zero); co = hxp hy hz entries per (component, octant)
+
+// ---- the 8-point butterfly --------------------------------------------------------------------------------------------------------------
+// index bit 0 / 1 / 2 = x / y / z.  Forward: in = values at the lower node (bit clear) and its mirror image (bit set), out = even (bit clear) and odd
+// (bit set) parts; a direction whose lower index is the centre of an odd line has no mirror: even = the value, odd = 0.
+__device__ __forceinline__ void bfly_fwd(double (&v)[8], const bool (&centre)[3]) {
+#pragma unroll
+  for (int bit = 0; bit < 3; ++bit) {
+    const int m = 1 << bit;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (!(i & m)) {
+      const double lo = v[i], hi = v[i | m];
+      v[i] = centre[bit] ? lo : lo + hi; v[i | m] = centre[bit] ? 0.0 : lo - hi;
+    }
+  }
+}
+// Backward: in = the even-mode / odd-mode partial sums (a, b), out = node values v_k = a + b, v_k' = a - b (centre: v = a, the mirror slot is unused)
+__device__ __forceinline__ void bfly_bwd(double (&v)[8], const bool (&centre)[3]) {
+#pragma unroll
+  for (int bit = 0; bit < 3; ++bit) {
+    const int m = 1 << bit;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (!(i & m)) {
+      const double a = v[i], b = v[i | m];
+      v[i] = centre[bit] ? a : a + b; v[i | m] = centre[bit] ? a : a - b;
+    }
+  }
+}
+struct OctPos {
+  int64_t node[8]; bool centre[3]; bool live[8]; double weight; bool valid;
+  // lower-octant position idx = (kz hy + ky) hxp + kx -> the eight mirror nodes; live[m]: node m is distinct from the ones with fewer mirrored directions; valid: not a row pad
+  __device__ __forceinline__ OctPos(const OctDims &D, int64_t idx) {
+    const int kx = (int)(idx % D.hxp), ky = (int)((idx / D.hxp) % D.hy), kz = (int)(idx / ((int64_t)D.hxp * D.hy));
+    valid = kx < D.hx;
+    const int mx = D.nx - 1 - kx, my = D.ny - 1 - ky, mz = D.nz - 1 - kz;
+    centre[0] = mx == kx; centre[1] = my == ky; centre[2] = mz == kz;
+    weight = (centre[0] ? 1.0 : 0.5) * (centre[1] ? 1.0 : 0.5) * (centre[2] ? 1.0 : 0.5);   // |v|^2 over a mirror orbit = weight * sum of the squared parity parts
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int x = (m & 1) ? mx : kx, y = (m & 2) ? my : ky, z = (m & 4) ? mz : kz;
+      node[m] = ((int64_t)z * D.ny + y) * D.nx + x;
+      live[m] = !((m & 1) && centre[0]) && !((m & 2) && centre[1]) && !((m & 4) && centre[2]);
+    }
+  }
+};
+
+// Thread mapping of the vector kernels: thread t <-> (lower-octant position t / 3, component t % 3), so that the lanes of a wave walk through the node-interleaved
+// vectors contiguously (dof = 3 node + c: 512 contiguous bytes per wave access, ascending for the lower nodes, descending for the mirror images) and through three
+// contiguous streams of every octant array.  (First version: one thread per position, all three components - 8-byte accesses at 24-byte stride: 170 us for the
+// direction update instead of 45.)
+#define PORO_OCT_LOOP(D) for (int64_t t_ = (int64_t)blockIdx.x * kBlock + threadIdx.x; t_ < 3 * (D).co; t_ += (int64_t)gridDim.x * kBlock)
+#define PORO_OCT_DECODE(D) const int64_t idx = t_ / 3; const int c = (int)(t_ - 3 * idx); const OctPos P(D, idx); if (!P.valid) continue;
+
+// q = H v: node-interleaved vector (dof = 3 node + c) -> octant form; masked dofs count as zero
+__global__ void __launch_bounds__(kBlock) k_fdmo_from_nodal(OctDims D, const double *__restrict__ v, const uint8_t *__restrict__ inert, double *__restrict__ q) {
+  PORO_OCT_LOOP(D) {
+    PORO_OCT_DECODE(D)
+    double w[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { const int64_t dof = P.node[m] * 3 + c; w[m] = (inert && inert[dof]) ? 0.0 : v[dof]; }
+    bfly_fwd(w, P.centre);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) q[(int64_t)(c * 8 + o) * D.co + idx] = w[o];
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_fdmo_to_nodal(OctDims D, const double *__restrict__ r, double *__restrict__ v) {
+  PORO_OCT_LOOP(D) {
+    PORO_OCT_DECODE(D)
+    double w[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) w[o] = r[(int64_t)(c * 8 + o) * D.co + idx];
+    bfly_bwd(w, P.centre);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) if (P.live[m]) v[P.node[m] * 3 + c] = w[m];
+  }
+}
+
+// ---- CG vector kernels with g, z in octant form (protocol of k_pcg_* in kernels_la.hip) ---------------------------------------------------
+// g = H (A x - b), zero on the inert (Dirichlet) dofs
+__global__ void __launch_bounds__(kBlock) k_fdmo_init_residual(OctDims D, double *__restrict__ g, const double *__restrict__ Ax, const double *__restrict__ b, const uint8_t *__restrict__ inert) {
+  PORO_OCT_LOOP(D) {
+    PORO_OCT_DECODE(D)
+    double w[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { const int64_t dof = P.node[m] * 3 + c; w[m] = (inert && inert[dof]) ? 0.0 : Ax[dof] - b[dof]; }
+    bfly_fwd(w, P.centre);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) g[(int64_t)(c * 8 + o) * D.co + idx] = w[o];
+  }
+}
+// d = -z (nodal); block partials of g.g and g.z
+__global__ void __launch_bounds__(kBlock) k_fdmo_first_direction(OctDims D, double *__restrict__ d, const double *__restrict__ g, const double *__restrict__ z, double *partials) {
+  __shared__ double sh[5];
+  double gg = 0, gz = 0;
+  PORO_OCT_LOOP(D) {
+    PORO_OCT_DECODE(D)
+    double w[8]; double s2 = 0;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { const int64_t at = (int64_t)(c * 8 + o) * D.co + idx; const double gv = g[at]; w[o] = z[at]; s2 = fma(gv, gv, s2); gz = fma(gv, w[o], gz); }
+    gg = fma(P.weight, s2, gg);
+    bfly_bwd(w, P.centre);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) if (P.live[m]) d[P.node[m] * 3 + c] = -w[m];
+  }
+  gg = block_sum(gg, sh); gz = block_sum(gz, sh);
+  store_partial(partials, gg); store_partial(partials + kMaxPartials, gz);
+}
+// g += alpha H (A d) and the partials of g.g (g.z follows in a plain dot of the two octant arrays once z = P^-1 g exists)
+__global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctDims D, PcgScalars *sc, int parity, double *__restrict__ g, const double *__restrict__ h, const uint8_t *__restrict__ inert, const double *partials_dh, double *partials_out) {
+  __shared__ double sh[5];
+  if (sc->done) return;
+  if (sc->finishing) { if (blockIdx.x == 0 && threadIdx.x == 0) sc->done = 1; return; }   // (see k_pcg_update_g_fused)
+  const double dh = sum_partials(partials_dh, sh);
+  const double alpha = sc->gh2[parity] / dh;
+  double gg = 0;
+  PORO_OCT_LOOP(D) {
+    PORO_OCT_DECODE(D)
+    // inert (Dirichlet) dofs: the residual stays exactly zero whatever the operator left in h.  The octant form exists only where every Dirichlet condition covers a
+    // pair of opposite faces (build_fdm_u), so the eight mirror images of a dof are inert together: one mask byte per thread
+    if (inert && inert[P.node[0] * 3 + c]) continue;
+    double w[8]; double s2 = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) w[m] = h[P.node[m] * 3 + c];
+    bfly_fwd(w, P.centre);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { const int64_t at = (int64_t)(c * 8 + o) * D.co + idx; const double gv = fma(alpha, w[o], g[at]); g[at] = gv; s2 = fma(gv, gv, s2); }
+    gg = fma(P.weight, s2, gg);
+  }
+  gg = block_sum(gg, sh);
+  store_partial(partials_out, gg);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
+}
+// x += alpha d, then d = beta d - H' z unless the solve just finished (k_pcg_update_d_fused with the explicit z in octant form)
+__global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars *sc, int parity, int it, double *__restrict__ x, double *__restrict__ d, const double *__restrict__ z, int64_t n_u, const double *partials_in) {
+  __shared__ double sh[5];
+  if (sc->done) return;
+  const double gg = sum_partials(partials_in, sh), gz = sum_partials(partials_in + kMaxPartials, sh);
+  const double res = sqrt(gg), gh_old = sc->gh2[parity], alpha = sc->alpha;
+  const bool conv = res <= sc->tol, fail = !conv && it >= sc->max_iter;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gg = gg; sc->gz = gz; sc->res = res; sc->it = it; }
+  if (conv || fail) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_u; i += (int64_t)gridDim.x * kBlock) x[i] = fma(alpha, d[i], x[i]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->converged = conv ? 1 : 0; sc->finishing = 1; }
+    return;
+  }
+  const double beta = gz / gh_old;
+  PORO_OCT_LOOP(D) {
+    PORO_OCT_DECODE(D)
+    double w[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) w[o] = z[(int64_t)(c * 8 + o) * D.co + idx];
+    bfly_bwd(w, P.centre);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) if (P.live[m]) {
+      const int64_t dof = P.node[m] * 3 + c;
+      const double dv = d[dof], xv = x[dof];
+      x[dof] = fma(alpha, dv, xv); d[dof] = fma(beta, dv, -w[m]);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->gh2[parity ^ 1] = gz; }
+}
+
+// ---- the transform pass --------------------------------------------------------------------------------------------------------------------
+struct OctPass {
+  int mode;                 // 0: contract columns, then rows (pass 1); 1: rows, eigenvalue scaling, rows (pass 2); 2: rows, then columns (pass 3)
+  int R, C;                 // valid rows / columns of a block (mode 1: C = columns of a full chunk, the last chunk has fewer)
+  int nt_r, nt_c;           // 16-wide tiles covering them
+  int kk1, kk2;             // k-steps (of 4) of the two GEMMs
+  int nblk;                 // blocks per (component, octant)
+  int64_t co_stride, blk_stride, row_stride;
+  int bit1, bit2;           // octant bit that selects the parity of the matrices of GEMM 1 / 2
+  int hx, pl;               // mode 1: columns of a plane = hx hy; a column's plane offset -> (my, mx)
+  const double *T1[3][2], *T2[3][2];                     // [component][parity], MFMA fragment order [tile][4 NT][64]
+  const double *lam_z[3][2]; double cz[3]; const double *bxy;   // mode 1: eigenvalues of the line direction; bxy[(4 c + (o & 3)) pl + column] = the other two directions' share
+  unsigned long long *stamps;   // diagnostic (PORO_FDMO_STAMPS): per block 8 words: 100 MHz time at start / block in LDS / GEMM 1 done / intermediate in LDS / GEMM 2 done / stored, HW_ID, XCC_ID
+};
+
+template <int NT> struct PassGeom {
+  static constexpr int PADN = 16 * NT, KKP = 4 * NT;
+  static constexpr int LDA = PADN + 2;                       // data as the A operand: lane (i, kq) reads [16 t + i][4 kk + kq]; LD = 2 * odd (mod 32) keeps a 32-lane group on 32 bank pairs
+  static constexpr int LDB = PADN + ((NT & 1) ? 0 : 16);     // data as the B operand: lane (j, kq) reads [4 kk + kq][16 w + j]; LD = 16 (mod 32)
+  static constexpr int LDMAX = LDA > LDB ? LDA : LDB;
+};
+
+// One item (= one (component, octant, block)) per workgroup; the hardware dispatcher balances the items over the CUs.
+// Workgroup shape (census of resident workgroups per CU, profiles/r03_lds_residency.txt): a 5-wave workgroup - the natural shape for 5 x 5 tiles - is given the
+// registers of an 8-wave one (two slots on every SIMD), which left 1.2-2 workgroups resident and the matrix pipe idle 55 % of the time (profiles/r03_fdmo_stamps_v1.txt).
+// 4-wave workgroups keep three resident at up to 128 registers, one wave of each on every SIMD.  So for NT = 5 FOUR waves share the 25 tiles: wave w owns tile row
+// (or column) w in full plus tile (4, w) [(w, 4)], and every wave also computes tile (4, 4), of which only the last wave's copy is used - 7 tiles per wave, no
+// branch inside the GEMM, 12 % more matrix work than the 25 tiles need.
+template <int NT, int MODE>
+__global__ void __launch_bounds__(64 * (NT < 4 ? NT : 4))
+k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_round) {
+  typedef PassGeom<NT> Gm;
+  constexpr int NW = NT < 4 ? NT : 4;                        // waves
+  constexpr bool EXTRA = NT > NW;                            // NT == 5: the fifth tile row / column is shared out
+  constexpr int XT = NT - 1;                                 // index of that tile row / column
+  constexpr int NACC = EXTRA ? NT + 2 : NT;
+  constexpr bool kColsFirst = MODE == 0, kColsSecond = MODE == 2;
+  constexpr int LD1 = kColsFirst ? Gm::LDA : Gm::LDB, LD2 = kColsSecond ? Gm::LDA : Gm::LDB;
+  constexpr int NS = EXTRA ? 2 : 1;                          // fragment streams per wave: its own tile row of T (and the shared one)
+  __shared__ double L[Gm::PADN * Gm::LDMAX];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.x % P.nblk, co = blockIdx.x / P.nblk, c = co >> 3, o = co & 7;
+  const int64_t base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
+  const int R = P.R, C = MODE == 1 ? min(P.C, P.pl - b * P.C) : P.C;
+  const double *__restrict__ T1 = P.T1[c][(o >> P.bit1) & 1] + lane, *__restrict__ T2 = P.T2[c][(o >> P.bit2) & 1] + lane;
+  auto stamp = [&](int k) { if (P.stamps && tid == 0) P.stamps[(int64_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime(); };
+  // All workgroups of the first round (three per CU) start together and would load, multiply and store in lockstep - memory and matrix phases then ADD instead of
+  // overlapping (measured: 29 us + 51 us = 82 us per pass).  The second / third workgroup of a CU therefore waits a third / two thirds of an item's lifetime.
+  if (stagger > 0 && (int)blockIdx.x < first_round) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)stagger * (((int)blockIdx.x * 3) / first_round);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
+  stamp(0);
+  // ---- block -> LDS, zero padded to PADN x PADN (the padding meets zero columns of T, but must be finite).  Rows are 16-byte aligned (even pitch, even chunk
+  //      offsets, even C): 16-byte loads and LDS stores, all loads in flight before the first LDS store ----
+  __builtin_amdgcn_s_setprio(3);   // the few instructions of the load phase go ahead of the co-resident workgroups' matrix streams
+  {
+    constexpr int HP = Gm::PADN / 2, TOT = Gm::PADN * HP, PER = (TOT + 64 * NW - 1) / (64 * NW);
+    double2 stage[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP);
+      stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP); if (e < TOT) *reinterpret_cast<double2 *>(&L[r * LD1 + c2]) = stage[u]; }
+  }
+  // transform-matrix fragments in two rotating register buffers of 4 k-steps: the 2 NT chunks of the two GEMMs form one sequence, and a buffer is refilled with the
+  // chunk after next as soon as the MFMAs that used it have been issued
+  double tf[2][NS][4];
+  auto load_chunk = [&](int buf, int step) {                 // step < NT: chunk `step` of T1, else chunk step - NT of T2
+    const double *__restrict__ T = step < NT ? T1 : T2; const int ch = step < NT ? step : step - NT;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tf[buf][0][k] = T[((int64_t)w * Gm::KKP + 4 * ch + k) * 64];
+      if constexpr (EXTRA) tf[buf][1][k] = T[((int64_t)XT * Gm::KKP + 4 * ch + k) * 64];
+    }
+  };
+  v4d acc[NACC];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = v4d{0, 0, 0, 0};
+  };
+  // one GEMM = NT chunks.  Every tile of the padded problem is computed (the padding is exact zeros: no predicates inside), only whole trailing k-steps are skipped.
+  //   contract columns: acc[t] = tile (t, w) = sum_k data(rows of tile t, k) T(rows of tile w, k); extra: acc[NT] = tile (w, XT), acc[NT + 1] = tile (XT, XT)
+  //   contract rows:    acc[u] = tile (w, u) = sum_k T(rows of tile w, k) data(k, columns of tile u); extra: acc[NT] = tile (XT, w), acc[NT + 1] = tile (XT, XT)
+  auto gemm = [&](auto contract_cols, auto ld_c, auto first_step_c, int kk_n) {
+    constexpr bool kCols = decltype(contract_cols)::value; constexpr int LD = decltype(ld_c)::value, S0 = decltype(first_step_c)::value;
+    const double *La = kCols ? L + j * LD + kq : L + kq * LD + j;
+    const double *Lw = kCols ? La + 16 * w * LD : La + 16 * w;                 // this wave's own tile row / column of the data (runtime w)
+#pragma unroll
+    for (int ch = 0; ch < NT; ++ch) {
+      constexpr int dummy = 0; (void)dummy;
+      const int buf = (S0 + ch) & 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int kk = 4 * ch + k;
+        if (ch < NT - 1 || k == 0 || kk < kk_n) {            // (kk_n >= KKP - 3 always: wave-uniform branches on the last three k-steps only)
+          double d[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) d[t] = kCols ? La[16 * t * LD + 4 * kk] : La[4 * kk * LD + 16 * t];
+          double dw = 0; if constexpr (EXTRA) dw = kCols ? Lw[4 * kk] : Lw[4 * kk * LD];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(d[t], tf[buf][0][k], acc[t], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][0][k], d[t], acc[t], 0, 0, 0);
+          if constexpr (EXTRA) {
+            acc[NT] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(dw, tf[buf][1][k], acc[NT], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][1][k], dw, acc[NT], 0, 0, 0);
+            acc[NT + 1] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(d[XT], tf[buf][1][k], acc[NT + 1], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][1][k], d[XT], acc[NT + 1], 0, 0, 0);
+          }
+        }
+      }
+      if (S0 + ch + 2 < 2 * NT) load_chunk(buf, S0 + ch + 2);
+    }
+  };
+  // accumulator -> element (16 tr + 4 q + kq, 16 tc + j) of tile (tr, tc)
+  auto tile_of = [&](int a, int &tr, int &tc, bool cols) {     // which tile accumulator a holds
+    if (a < NT) { tr = cols ? a : w; tc = cols ? w : a; }
+    else if (a == NT) { tr = cols ? w : XT; tc = cols ? XT : w; }
+    else { tr = XT; tc = XT; }
+  };
+  typedef std::integral_constant<bool, kColsFirst> CF; typedef std::integral_constant<int, LD1> L1c;
+  typedef std::integral_constant<bool, kColsSecond> CS; typedef std::integral_constant<int, LD2> L2c;
+  load_chunk(0, 0); load_chunk(1, 1);
+  zero_acc();
+  __builtin_amdgcn_s_setprio(0);
+  __syncthreads();
+  stamp(1);
+  gemm(CF{}, L1c{}, std::integral_constant<int, 0>{}, P.kk1);
+  __syncthreads();                                   // everybody has finished reading the input block
+  stamp(2);
+  // ---- first result -> LDS in the layout of the second GEMM (MODE 1: divided by the eigenvalue sums on the way) ----
+  if constexpr (MODE == 1) {
+    // rows of this wave's tiles: tile row w (and the shared row XT); columns: tile column of the accumulator.  One accumulator at a time (sched_barrier), otherwise
+    // the eigenvalue loads of all seven pile up in registers
+    const double *lamz = P.lam_z[c][(o >> 2) & 1], *bx = P.bxy + (int64_t)(4 * c + (o & 3)) * P.pl;
+    const double czc = P.cz[c];
+    double lzw[4], lzx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { lzw[q] = czc * lamz[16 * w + 4 * q + kq]; lzx[q] = EXTRA ? czc * lamz[16 * XT + 4 * q + kq] : 0.0; }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      int tr, tc; tile_of(a, tr, tc, false);
+      if (a == NT + 1 && w != NW - 1) continue;              // tile (XT, XT): every wave has computed it, the last one writes it
+      const double bxy = bx[min(b * P.C + 16 * tc + j, P.pl - 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // reciprocal by v_rcp_f64 + one Newton step; modes that do not exist carry lam = inf and give exactly 0
+        const double den = (a < NT ? lzw[q] : lzx[q]) + bxy;
+        double r = __builtin_amdgcn_rcp(den);
+        r = den < 1e300 ? fma(r, fma(-den, r, 1.0), r) : 0.0;
+        L[(16 * tr + 4 * q + kq) * LD2 + 16 * tc + j] = acc[a][q] * r;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      int tr, tc; tile_of(a, tr, tc, kColsFirst);
+      if (a == NT + 1 && w != NW - 1) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) L[(16 * tr + 4 * q + kq) * LD2 + 16 * tc + j] = acc[a][q];
+    }
+  }
+  zero_acc();
+  __syncthreads();
+  stamp(3);
+  gemm(CS{}, L2c{}, std::integral_constant<int, NT>{}, P.kk2);
+  if (P.stamps) { __syncthreads(); stamp(4); }
+  // ---- store ----
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    int tr, tc; tile_of(a, tr, tc, kColsSecond);
+    if (a == NT + 1 && w != NW - 1) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int r = 16 * tr + 4 * q + kq, cc = 16 * tc + j; if (r < R && cc < C) out[base + (int64_t)r * P.row_stride + cc] = acc[a][q]; }
+  }
+  if (P.stamps) {
+    __builtin_amdgcn_s_waitcnt(0); __syncthreads(); stamp(5);
+    if (tid == 0) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); P.stamps[(int64_t)blockIdx.x * 8 + 6] = hw; P.stamps[(int64_t)blockIdx.x * 8 + 7] = xcc; }
+  }
+}
+
+template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out) {
+  static int n_cu = 0;
+  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t prop; n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
+  // first-round stagger in 100 MHz ticks per slot; only where there is more than one round of full-size items
+  static const int stagger = std::getenv("PORO_FDMO_STAGGER") ? std::atoi(std::getenv("PORO_FDMO_STAGGER")) : 800;
+  const int first_round = std::min(n_items, 3 * n_cu), stg = (NT == 5 && n_items > 3 * n_cu) ? stagger : 0;
+  const dim3 grid((unsigned)n_items), block(64 * (NT < 4 ? NT : 4));
+  if (P.mode == 0) hipLaunchKernelGGL((k_fdmo_pass<NT, 0>), grid, block, 0, s, P, in, out, stg, first_round);
+  else if (P.mode == 1) hipLaunchKernelGGL((k_fdmo_pass<NT, 1>), grid, block, 0, s, P, in, out, stg, first_round);
+  else hipLaunchKernelGGL((k_fdmo_pass<NT, 2>), grid, block, 0, s, P, in, out, stg, first_round);
+}
+void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const double *in, double *out) {
+  switch (nt) {
+    case 1: launch_pass<1>(s, P, n_blocks, in, out); break;
+    case 2: launch_pass<2>(s, P, n_blocks, in, out); break;
+    case 3: launch_pass<3>(s, P, n_blocks, in, out); break;
+    case 4: launch_pass<4>(s, P, n_blocks, in, out); break;
+    case 5: launch_pass<5>(s, P, n_blocks, in, out); break;
+    default: throw Error("fdmo: half lines of more than 80 entries");
+  }
+}
+inline int oct_grid(int64_t co) { return (int)std::min<int64_t>((3 * co + kBlock - 1) / kBlock, kMaxPartials); }   // threads = positions x components, as many per thread as the partial slots demand
+OctDims dims_of(const FdmOct &O) { return OctDims{O.n[0], O.n[1], O.n[2], O.h[0], O.h[1], O.h[2], O.hxp, O.co_stride}; }
+
+}  // namespace
+
+bool fdmo_usable(int dim, const int nn[3]) {
+  if (dim != 3) return false;
+  for (int d = 0; d < 3; ++d) if ((nn[d] + 1) / 2 > 80 || nn[d] < 2) return false;
+  return true;
+}
+
+void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s) {
+  int hmax = 1;
+  for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = (nn[d] + 1) / 2; hmax = std::max(hmax, O.h[d]); for (int c = 0; c < 3; ++c) O.coef[c][d] = coef[c][d]; }
+  O.nt = (hmax + 15) / 16;
+  O.hxp = (O.h[0] + 1) & ~1;
+  O.co_stride = (int64_t)O.hxp * O.h[1] * O.h[2]; O.n_oct = 24 * O.co_stride;
+  O.g.alloc(O.n_oct); O.z.alloc(O.n_oct); O.t.alloc(O.n_oct);
+  O.g.zero(s); O.z.zero(s); O.t.zero(s);
+}
+
+bool fdmo_upload_dir(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn) {
+  const int h = (nn + 1) / 2, nt = O.nt, kkp = 4 * nt, padn = 16 * nt;
+  if (nn != O.n[dir]) throw Error("fdmo_upload_dir: line length mismatch");
+  std::vector<int> grp[2];
+  for (int m = 0; m < nn; ++m) {
+    if (!(lam[m] < 1e300)) continue;              // removed modes
+    double ds = 0, da = 0, nrm = 0;
+    for (int k = 0; k < nn; ++k) { const double a = S[(size_t)k * nn + m], b = S[(size_t)(nn - 1 - k) * nn + m]; ds += (a - b) * (a - b); da += (a + b) * (a + b); nrm += a * a; }
+    if (ds <= 1e-20 * nrm) grp[0].push_back(m); else if (da <= 1e-20 * nrm) grp[1].push_back(m); else return false;
+  }
+  for (int p = 0; p < 2; ++p) {
+    if ((int)grp[p].size() > h) return false;
+    // forward F[m][k] = S[k][mode m] (rows = modes of the parity group, columns = lower-half nodes), backward B[k][m] = S[k][mode m]; both as [tile][4 NT][64]:
+    // lane l of fragment (tile, kk) holds element (16 tile + (l & 15), 4 kk + (l >> 4))
+    std::vector<double> F((size_t)nt * kkp * 64, 0.0), B((size_t)nt * kkp * 64, 0.0), lp(padn + 16, std::numeric_limits<double>::infinity());
+    const int ng = (int)grp[p].size();
+    for (int t = 0; t < nt; ++t) for (int kk = 0; kk < kkp; ++kk) for (int l = 0; l < 64; ++l) {
+      const int r = 16 * t + (l & 15), cc = 4 * kk + (l >> 4);
+      const size_t at = ((size_t)t * kkp + kk) * 64 + l;
+      if (r < ng && cc < h) F[at] = S[(size_t)cc * nn + grp[p][r]];
+      if (r < h && cc < ng) B[at] = S[(size_t)r * nn + grp[p][cc]];
+    }
+    for (int m = 0; m < ng; ++m) lp[m] = lam[grp[p][m]];
+    O.h_lam[comp][dir][p] = lp;
+    O.fwd[comp][dir][p].upload(F); O.bwd[comp][dir][p].upload(B); O.lam[comp][dir][p].upload(lp);
+  }
+  return true;
+}
+
+void fdmo_finalize(FdmOct &O) {
+  const int hx = O.h[0], hy = O.h[1], hxp = O.hxp; const size_t pl = (size_t)hxp * hy;
+  std::vector<double> B(12 * pl, 1.0);             // (row pads: any finite non-zero value, their data are zeros)
+  for (int c = 0; c < 3; ++c) for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) for (int my = 0; my < hy; ++my) for (int mx = 0; mx < hx; ++mx)
+    B[(size_t)(4 * c + 2 * py + px) * pl + (size_t)my * hxp + mx] = O.coef[c][0] * O.h_lam[c][0][px][mx] + O.coef[c][1] * O.h_lam[c][1][py][my];
+  O.bxy.upload(B);
+}
+
+void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch) {
+  static int stamp_calls = 0; const char *stamp_path = std::getenv("PORO_FDMO_STAMPS");
+  const bool stamping = stamp_path && ++stamp_calls == 3;          // diagnostic: the third application of the process writes its per-block time stamps
+  DevBuf<unsigned long long> stamps; std::vector<std::pair<int, int64_t>> stamp_off;
+  const int nt = O.nt, hx = O.h[0], hy = O.h[1], hz = O.h[2], hxp = O.hxp;
+  auto tiles = [](int n) { return (n + 15) / 16; };
+  auto ksteps = [](int n) { return (n + 3) / 4; };
+  OctPass P{};
+  P.co_stride = O.co_stride; P.hx = hxp; P.pl = hxp * hy;
+  P.bxy = O.bxy.p;
+  for (int c = 0; c < 3; ++c) { P.cz[c] = O.coef[c][2]; for (int p = 0; p < 2; ++p) P.lam_z[c][p] = O.lam[c][2][p].p; }
+  // pass 1: per z-plane, X[ky][kx] -> Fy (X Fx^T)
+  P.mode = 0; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 0; P.bit2 = 1;
+  for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][0][p].p; P.T2[c][p] = O.fwd[c][1][p].p; }
+  if (stamping) { stamps.alloc((size_t)8 * 24 * (O.h[2] + (hxp * hy + 16 * nt - 1) / (16 * nt) + O.h[2])); stamps.zero(s); }
+  P.stamps = stamping ? stamps.p : nullptr; stamp_off.push_back({24 * P.nblk, 0});
+  launch_pass_nt(s, nt, P, 24 * P.nblk, g_oct, scratch);
+  // pass 2: per chunk of 16 NT columns of a (component, octant) block, X[kz][col] -> Bz scale (Fz X), in place
+  P.mode = 1; P.R = hz; P.C = 16 * nt; P.nt_r = tiles(hz); P.nt_c = nt; P.kk1 = ksteps(hz); P.kk2 = ksteps(hz); P.nblk = (hxp * hy + 16 * nt - 1) / (16 * nt); P.blk_stride = 16 * nt; P.row_stride = (int64_t)hxp * hy; P.bit1 = 2; P.bit2 = 2;
+  for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][2][p].p; P.T2[c][p] = O.bwd[c][2][p].p; }
+  if (stamping) P.stamps = stamps.p + 8 * (int64_t)(24 * hz); stamp_off.push_back({24 * P.nblk, 8 * (int64_t)(24 * hz)});
+  launch_pass_nt(s, nt, P, 24 * P.nblk, scratch, scratch);
+  // pass 3: per z-plane, X[my][mx] -> (By X) Bx^T
+  P.mode = 2; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hy); P.kk2 = ksteps(hx); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 1; P.bit2 = 0;
+  for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.bwd[c][1][p].p; P.T2[c][p] = O.bwd[c][0][p].p; }
+  if (stamping) P.stamps = stamps.p + 8 * (int64_t)(24 * hz + stamp_off[1].first); stamp_off.push_back({24 * P.nblk, 8 * (int64_t)(24 * hz + stamp_off[1].first)});
+  launch_pass_nt(s, nt, P, 24 * P.nblk, scratch, z_oct);
+  if (stamping) {
+    PORO_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h(stamps.n); PORO_HIP(hipMemcpy(h.data(), stamps.p, stamps.n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE *f = std::fopen(stamp_path, "w")) {
+      for (int pass = 0; pass < 3; ++pass) for (int b = 0; b < stamp_off[pass].first; ++b) {
+        const unsigned long long *r = h.data() + stamp_off[pass].second + 8 * (int64_t)b;
+        std::fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu %llu %llu\n", pass, b, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+      }
+      std::fclose(f);
+    }
+  }
+}
+
+void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v, double *q) { hipLaunchKernelGGL(k_fdmo_from_nodal, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), v, (const uint8_t *)nullptr, q); }
+void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r, double *v) { hipLaunchKernelGGL(k_fdmo_to_nodal, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), r, v); }
+void fdmo_init_residual(hipStream_t s, const FdmOct &O, double *g, const double *Ax, const double *b, const uint8_t *inert) {
+  hipLaunchKernelGGL(k_fdmo_init_residual, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), g, Ax, b, inert);
+}
+void fdmo_first_direction(hipStream_t s, const FdmOct &O, double *d, const double *g, const double *z, double *partials) {
+  hipLaunchKernelGGL(k_fdmo_first_direction, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), d, g, z, partials);
+}
+void fdmo_update_g(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, double *g, const double *h, const uint8_t *inert, const double *partials_dh, double *partials_out) {
+  hipLaunchKernelGGL(k_fdmo_update_g, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), sc, parity, g, h, inert, partials_dh, partials_out);
+}
+void fdmo_update_d(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, int it, double *x, double *d, const double *z, const double *partials_in) {
+  hipLaunchKernelGGL(k_fdmo_update_d, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), sc, parity, it, x, d, z, (int64_t)3 * O.n[0] * O.n[1] * O.n[2], partials_in);
+}
+
+}  // namespace poro
