@@ -8,7 +8,13 @@
  * Every entry point below names the reference member (file:line) it replaces.
  * Signatures use plain pointers and sizes only (no C++/torch types); the
  * library owns all device memory behind the opaque handle, the caller owns the
- * host arrays it passes in.  All calls are synchronous at return.
+ * host arrays it passes in.  Entry points that hand something back to the host (a norm, a
+ * poro_solve_info, a vector, a matrix) return when the device has produced it; entry points that
+ * only transform device-resident state (assembly, vector updates, the `distribute` at the end of a
+ * solve) are ordered on the context's stream and may return before the device has finished - exactly
+ * what lets the fixed-stress loop run without idling the GPU between calls.  poro_ctx_synchronize()
+ * waits for everything enqueued so far; errors of asynchronous work surface at the next
+ * synchronising call.
  *
  * Conventions fixed by this ABI (the reference leaves them to deal.II):
  *   - local scalar nodes of a cell are lexicographic on the (k+1)^dim tensor
@@ -223,6 +229,8 @@ int  poro_abi_version(void);
  * selects assembled CSR or the matrix-free A_u (needs desc->box.enabled). */
 int  poro_ctx_create(const poro_desc *desc, int device, int operator_mode, poro_ctx **out);
 void poro_ctx_destroy(poro_ctx *ctx);
+/* wait until the device has finished everything the context has enqueued (see the note on synchronisation at the top) */
+int  poro_ctx_synchronize(poro_ctx *ctx);
 
 /* multi-GPU wiring.  id is the 128-byte ncclUniqueId from rank 0. */
 int  poro_comm_unique_id(void *id128);

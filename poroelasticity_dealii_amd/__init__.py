@@ -89,7 +89,7 @@ SENDRECV_FN = C.CFUNCTYPE(None, _dp, _dp, C.c_int64, C.c_int32, C.c_void_p)
 
 # every symbol include/poroel_hip.h declares (checked by the CPU test-suite against the built library)
 HIP_SYMBOLS = [
-    "poro_last_error", "poro_abi_version", "poro_ctx_create", "poro_ctx_destroy", "poro_comm_unique_id", "poro_ctx_comm_init_rccl",
+    "poro_last_error", "poro_abi_version", "poro_ctx_create", "poro_ctx_destroy", "poro_ctx_synchronize", "poro_comm_unique_id", "poro_ctx_comm_init_rccl",
     "poro_ctx_comm_init_callbacks", "poro_vec_set", "poro_vec_get", "poro_vec_fill", "poro_vec_copy", "poro_vec_axpy", "poro_vec_norm",
     "poro_state_save", "poro_state_restore", "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_apply_boundary_values", "poro_pres_assemble_jacobian", "poro_pres_solve",
     "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain", "poro_get_effective_stresses",
@@ -114,6 +114,7 @@ def load_hip():
         L.poro_ctx_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.poro_ctx_destroy.argtypes = [C.c_void_p]
         L.poro_ctx_destroy.restype = None
+        L.poro_ctx_synchronize.argtypes = [C.c_void_p]
         L.poro_comm_unique_id.argtypes = [C.c_void_p]
         L.poro_ctx_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p]
         L.poro_ctx_comm_init_callbacks.argtypes = [C.c_void_p, ALLREDUCE_FN, SENDRECV_FN, C.c_void_p]
@@ -316,6 +317,10 @@ class Context:
         if self.ptr:
             self.L.poro_ctx_destroy(self.ptr)
             self.ptr = None
+
+    def synchronize(self):
+        """wait for everything the context has enqueued (device-only entry points are stream-ordered)"""
+        self._chk(self.L.poro_ctx_synchronize(self.ptr))
 
     def _len(self, which):
         return self.n_u if which in (VEC_U, VEC_RHS_U, VEC_DIAG_U) else self.n_p

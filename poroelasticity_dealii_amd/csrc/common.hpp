@@ -42,6 +42,11 @@ struct PcgScalars {
   int32_t it, done, converged, max_iter, finishing, pad_;
 };
 
+// Mailbox in pinned, device-visible host memory: a one-block kernel at the end of an enqueued sequence copies a few scalars (and optionally the PCG state) into it and
+// then raises `seq` with a system-scope release; the host spins on `seq` instead of issuing a device-to-host copy + stream synchronisation (which idled the GPU
+// for 20-60 us per round trip, 25 times per time step: profiles/r02_gpu_idle_gaps.txt).
+struct Mailbox { volatile unsigned long long seq; unsigned long long pad_; double vals[16]; PcgScalars sc; };
+
 // device-side state of the single-reduction PCG (partitioned runs)
 struct Cg1State { double gamma_old, alpha_old, alpha, beta, tol, res0, res; int32_t it, done, converged, pad_; };
 
@@ -147,6 +152,8 @@ struct BoxDev { int enabled = 0; int n[3] = {1, 1, 1}; int nn[3] = {1, 1, 1}; do
 }  // namespace poro
 
 struct poro_ctx {
+  poro_ctx() = default; poro_ctx(const poro_ctx &) = delete; poro_ctx &operator=(const poro_ctx &) = delete;
+  ~poro_ctx() { if (mailbox) (void)hipHostFree(mailbox); }
   int device = 0, operator_mode = PORO_OP_CSR;
   hipStream_t stream = nullptr;
   int dim = 2, k_u = 2, ns_u = 9, ns_p = 4, dpc_u = 18, dpc_p = 4, nv = 4;
@@ -188,6 +195,7 @@ struct poro_ctx {
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
+  poro::Mailbox *mailbox = nullptr; unsigned long long mb_seq = 0;   // pinned host memory (hipHostMalloc), device-visible at the same address
   bool cheb_z1_ready = false;   // single-reduction PCG: the update kernel has already stored the first Chebyshev iterate of the coming preconditioner call
   int timing_stride = 1;   // events on every timing_stride-th launch of a family (poro_timers_enable)
   poro::DevBuf<double> cheb_side_lo, cheb_side_hi;   // partial products of the fused Chebyshev kernel on the shared planes (slab partitions)
@@ -206,12 +214,14 @@ namespace poro {
 
 // ---- kernels_la.hip -----------------------------------------------------------------------------
 void la_fill(hipStream_t s, double *x, double v, int64_t n);
+// copy n <= 16 doubles from `src` (device) and optionally *sc into the host mailbox, then publish sequence number `seq` (system-scope release)
+void la_post(hipStream_t s, Mailbox *mb, unsigned long long seq, const double *src, int n, const PcgScalars *sc);
 void la_copy(hipStream_t s, double *y, const double *x, int64_t n);
 void la_axpy(hipStream_t s, double *y, double a, const double *x, int64_t n);
 void la_add_range(hipStream_t s, double *y, const double *x, int64_t n);
 void la_add_two_ranges(hipStream_t s, double *y0, const double *x0, double *y1, const double *x1, int64_t n);
 // partials-based reductions; results land in red[slot..] after la_reduce_finish
-void la_dot_partials(hipStream_t s, const double *a, const double *b, int64_t n, double *partials /*[kMaxPartials]*/);
+void la_dot_partials(hipStream_t s, const double *a, const double *b, int64_t n, double *partials /*[kMaxPartials]*/, const PcgScalars *gate = nullptr /* no-op once gate->done / finishing */);
 void la_norm_partials(hipStream_t s, const double *a, int64_t n, double *partials_l2, double *partials_inf);
 void la_reduce_finish(hipStream_t s, const double *partials, int n_sets, double *red /*[n_sets]*/, int max_not_sum_mask);
 void la_csr_spmv(hipStream_t s, const CsrDev &A, const double *val, const double *x, double *y);
@@ -319,7 +329,7 @@ void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t 
 // half-size transforms of (component, direction) from the generalised eigenvectors S (nn x nn row-major, every mode symmetric or antisymmetric) and eigenvalues lam
 bool fdmo_upload_dir(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn);
 void fdmo_finalize(FdmOct &O);   // after every (component, direction) has been uploaded: derived tables
-void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch_oct);   // z = blockdiag(A_cc)^-1 g, all in octant form
+void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch_oct, const PcgScalars *gate = nullptr);   // z = blockdiag(A_cc)^-1 g, all in octant form; gate: no-op once gate->done / finishing
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v_nodal, double *q_oct);   // q = H v (node-interleaved vector -> octant form)
 void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r_oct, double *v_nodal);     // v = H^-1-form of the backward transform: v_k = a + b, v_k' = a - b
 // the vector kernels of pcg() with g / z in octant form (same device-side scalar protocol as their nodal counterparts in kernels_la.hip)

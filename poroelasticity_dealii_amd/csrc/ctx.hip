@@ -150,6 +150,25 @@ struct EventPair {
   EventPair(const EventPair &) = delete; EventPair &operator=(const EventPair &) = delete;
 };
 
+// ---- device -> host scalars without a copy engine or a stream synchronisation (Mailbox, common.hpp) ------------------------------------------
+// enqueue the publishing kernel behind everything that is in the stream, then spin on the sequence number in pinned host memory
+void post_and_wait(poro_ctx *c, const double *dev_src, int n, const PcgScalars *sc = nullptr) {
+  if (n > 16) throw Error("post_and_wait: at most 16 scalars");
+  const unsigned long long want = ++c->mb_seq;
+  la_post(c->stream, c->mailbox, want, dev_src, n, sc);
+  PORO_HIP(hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now(); unsigned spins = 0;
+  while (__atomic_load_n(const_cast<unsigned long long *>(&c->mailbox->seq), __ATOMIC_ACQUIRE) != want) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xfffff) == 0) {   // every ~million spins: is the device still alive?  (a faulted kernel would otherwise leave the host spinning for ever)
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) throw Error(std::string("device failed while the host waited for its answer: ") + hipGetErrorString(q));
+      if (q == hipSuccess && __atomic_load_n(const_cast<unsigned long long *>(&c->mailbox->seq), __ATOMIC_ACQUIRE) != want) throw Error("mailbox: the stream drained without publishing the expected sequence number");
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600.0) throw Error("mailbox: no answer from the device within 600 s");
+    }
+  }
+}
+
 // ---- communication: sum the neighbour's partial rows on the shared node planes; all-reduce scalars -------------------
 // general partition: per-neighbour interface lists (poro_partition.shared_*).  One pack kernel, one grouped exchange with all neighbours, one kernel
 // that sums own + received partial rows in ascending rank order.
@@ -393,7 +412,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   const bool multi = c->comm.multi();
   double *part = c->partials.p, *red = c->red.p; PcgScalars *sc = c->scal.p;
   double *part_dh = part + 3 * (size_t)kMaxPartials;      // slots of the fused / separate d.h partials
-  EventPair ev(c); const hipEvent_t e0 = ev.e0, e1 = ev.e1; PORO_HIP(hipEventRecord(e0, s));
+  const auto t_start = std::chrono::steady_clock::now();
   int64_t applies = 0;
   // g = A x - b ; d = -P^-1 g ; gh = g.P^-1 g
   apply(x, h, nullptr); ++applies;
@@ -428,20 +447,20 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
       if (multi) { pcg_scalars_sum(s, part_dh, 1, red); allreduce_sum(c, red, 1); }
       if (oct) fdmo_update_g(s, *oct, sc, (it - 1) & 1, g, h, diag.inert, part_dh, part);
       else pcg_update_g_fused(s, sc, (it - 1) & 1, g, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
-      if (precond && !(*precond)(g, zbuf, part + kMaxPartials)) la_dot_partials(s, g, zbuf, oct ? oct->n_oct : n_own, part + kMaxPartials);
+      if (precond && !(*precond)(g, zbuf, part + kMaxPartials)) la_dot_partials(s, g, zbuf, oct ? oct->n_oct : n_own, part + kMaxPartials, precond_gated ? sc : nullptr);
       if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
       if (oct) fdmo_update_d(s, *oct, sc, (it - 1) & 1, it, x, d, zbuf, part);
       else pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
-    PORO_HIP(hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
+    post_and_wait(c, nullptr, 0, sc); hs = c->mailbox->sc;
     if (hs.done || hs.finishing) break;
     if (expect > 0) batch = cheap_overshoot ? 3 : 1;
     else if (batch < 32) batch *= 2;
   }
   if (its_hint) { its_hint[1] = its_hint[0]; its_hint[0] = hs.it; }
-  PORO_HIP(hipEventRecord(e1, s)); PORO_HIP(hipEventSynchronize(e1));
-  float ms = 0; PORO_HIP(hipEventElapsedTime(&ms, e0, e1));
-  if (info) { info->iterations = hs.it; info->converged = hs.converged; info->initial_residual = hs.res0; info->final_residual = hs.res; info->seconds = ms * 1e-3;
+  // (the last poll returned after the finishing iteration: the solve is complete on the device; wall time of the solve on the host clock)
+  if (info) { info->iterations = hs.it; info->converged = hs.converged; info->initial_residual = hs.res0; info->final_residual = hs.res;
+              info->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
               info->operator_applications = hs.it + 1;   // initial residual + one per iteration (launches enqueued behind the finishing iteration are no-ops and are not counted)
               (void)applies; }
   return hs.converged ? 0 : 1;
@@ -470,8 +489,8 @@ void build_ssor_levels(poro_ctx *c, CsrDev &A) {
 double dot_host(poro_ctx *c, const double *a, const double *b, int64_t n) {
   la_dot_partials(c->stream, a, b, n, c->partials.p); la_reduce_finish(c->stream, c->partials.p, 1, c->red.p, 0);
   allreduce_sum(c, c->red.p, 1);
-  double h; PORO_HIP(hipMemcpyAsync(&h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
-  return h;
+  post_and_wait(c, c->red.p, 1);
+  return c->mailbox->vals[0];
 }
 // SolverCG<>::solve with an explicit preconditioner z = P^-1 g, host-driven scalars.  Used where an application of P^-1 is many
 // launches anyway (SSOR sweeps) or where only a handful of iterations happen (fast diagonalisation).  Partitioned runs: `apply` and
@@ -1054,6 +1073,7 @@ int poro_ctx_create(const poro_desc *desc, int device, int operator_mode, poro_c
     c->device = device; c->operator_mode = operator_mode;
     PORO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     kron_prepare_device();   // function attributes are per device: opt in to the large dynamic LDS on THIS one
+    { void *mbp = nullptr; PORO_HIP(hipHostMalloc(&mbp, sizeof(Mailbox), hipHostMallocDefault)); std::memset(mbp, 0, sizeof(Mailbox)); c->mailbox = static_cast<Mailbox *>(mbp); }
     setup(c.get(), desc);
     *out = c.release();
     return 0;
@@ -1123,6 +1143,8 @@ int poro_ctx_comm_init_rccl(poro_ctx *c, const void *id128) {
 }
 int poro_ctx_comm_init_callbacks(poro_ctx *c, poro_allreduce_fn ar, poro_sendrecv_fn sr, void *user) { c->comm.ar = ar; c->comm.sr = sr; c->comm.user = user; return 0; }
 
+int poro_ctx_synchronize(poro_ctx *c) { return guarded([&] { PORO_HIP(hipSetDevice(c->device)); PORO_HIP(hipStreamSynchronize(c->stream)); return 0; }); }
+
 int poro_vec_set(poro_ctx *c, int which, const double *host, int64_t n) {
   return guarded([&] { PORO_HIP(hipSetDevice(c->device)); if (vec_len(c, which) != n) throw Error("vector length mismatch"); PORO_HIP(hipMemcpyAsync(vec(c, which), host, n * sizeof(double), hipMemcpyHostToDevice, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream)); return 0; });
 }
@@ -1148,8 +1170,8 @@ int poro_vec_norm(poro_ctx *c, int which, double *l2, double *linf) {
     la_norm_partials(c->stream, vec(c, which), owned(c, n, plane), c->partials.p, c->partials.p + kMaxPartials);
     la_reduce_finish(c->stream, c->partials.p, 2, c->red.p, 2);
     allreduce_sum(c, c->red.p, 1);   // linf stays rank-local under a partition (reporting only, PoroelasticityFSS.h:387-389)
-    double h[2]; PORO_HIP(hipMemcpyAsync(h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, c->stream)); PORO_HIP(hipStreamSynchronize(c->stream));
-    if (l2) *l2 = std::sqrt(h[0]); if (linf) *linf = h[1]; return 0;
+    post_and_wait(c, c->red.p, 2);
+    if (l2) *l2 = std::sqrt(c->mailbox->vals[0]); if (linf) *linf = c->mailbox->vals[1]; return 0;
   });
 }
 
@@ -1275,7 +1297,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
       }
       la_cons_reduce(s, c->cons_u, rhs);
     }
-    PORO_HIP(hipStreamSynchronize(s));
+    // stream-ordered: the right-hand side is consumed by kernels of the same stream (a caller that wants the host to wait calls poro_ctx_synchronize)
     return 0;
   });
 }
@@ -1426,21 +1448,21 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       (void)applies0;
       la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
       la_cons_expand(c->stream, c->cons_u, vec(c, PORO_VEC_U), true);
-      PORO_HIP(hipStreamSynchronize(c->stream));
-      return rc;
+      return rc;   // (stream-ordered: pcg() returned after the finishing iteration, `distribute` follows in the stream)
     }
     if (opts->preconditioner == PORO_PREC_FDM) {
       // z = blockdiag(A_cc)^-1 g by fast diagonalisation: the same device-controlled SolverCG recurrence with an explicit preconditioner vector
       build_fdm_u(c);
       const FdmOct *oct = c->fdm_oct.built ? &c->fdm_oct : nullptr;
-      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) {
-        if (oct) { Timed tm(c, "precondition_u_fdm"); fdmo_apply(c->stream, *oct, g, z, c->fdm_oct.t.p); }   // g, z in octant form: three contiguous sweeps
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *in_iteration) {
+        // g, z in octant form: three contiguous sweeps; inside the iteration the launches are gated on the device-side "solve finished" flag (before
+        // pcg_scalars_start it still holds the previous solve's state)
+        if (oct) { Timed tm(c, "precondition_u_fdm"); fdmo_apply(c->stream, *oct, g, z, c->fdm_oct.t.p, in_iteration ? c->scal.p : nullptr); }
         else fdm_precondition_u(c, g, z);
         return false; };
       DiagVec dz; dz.full = c->dinv_u.p; dz.ncomp = c->dim; dz.inert = c->dir_mask.p; dz.z = c->wz_u.p;
-      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_fdm_u, false, oct);
+      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_fdm_u, oct != nullptr /* every launch of an iteration is gated: overshooting is cheap */, oct);
       la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
-      PORO_HIP(hipStreamSynchronize(c->stream));
       return rc;
     }
     DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim; dv.inert = c->cons_u.inert.p;
@@ -1448,7 +1470,6 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dv, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, nullptr, c->pcg_hint_u);
     la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);   // constraints.distribute (:306)
     la_cons_expand(c->stream, c->cons_u, vec(c, PORO_VEC_U), true);
-    PORO_HIP(hipStreamSynchronize(c->stream));
     return rc;
   });
 }
@@ -1469,8 +1490,8 @@ int poro_pres_assemble_residual(poro_ctx *c, double dt, double *l2) {
     la_dot_partials(s, R, R, owned(c, c->n_p, c->comm.part.plane_p), c->partials.p);
     la_reduce_finish(s, c->partials.p, 1, c->red.p, 0);
     allreduce_sum(c, c->red.p, 1);
-    double h; PORO_HIP(hipMemcpyAsync(&h, c->red.p, sizeof(h), hipMemcpyDeviceToHost, s)); PORO_HIP(hipStreamSynchronize(s));
-    if (l2) *l2 = std::sqrt(h);
+    post_and_wait(c, c->red.p, 1);
+    if (l2) *l2 = std::sqrt(c->mailbox->vals[0]);
     return 0;
   });
 }

@@ -206,6 +206,7 @@ struct OctPass {
   int hx, pl;               // mode 1: columns of a plane = hx hy; a column's plane offset -> (my, mx)
   const double *T1[3][2], *T2[3][2];                     // [component][parity], MFMA fragment order [tile][4 NT][64]
   const double *lam_z[3][2]; double cz[3]; const double *bxy;   // mode 1: eigenvalues of the line direction; bxy[(4 c + (o & 3)) pl + column] = the other two directions' share
+  const PcgScalars *gate;       // inside a PCG iteration: the launch is a no-op once the solve has finished (the host enqueues iterations ahead of the device-side stopping test)
   unsigned long long *stamps;   // diagnostic (PORO_FDMO_STAMPS): per block 8 words: 100 MHz time at start / block in LDS / GEMM 1 done / intermediate in LDS / GEMM 2 done / stored, HW_ID, XCC_ID
 };
 
@@ -234,6 +235,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_rou
   constexpr int LD1 = kColsFirst ? Gm::LDA : Gm::LDB, LD2 = kColsSecond ? Gm::LDA : Gm::LDB;
   constexpr int NS = EXTRA ? 2 : 1;                          // fragment streams per wave: its own tile row of T (and the shared one)
   __shared__ double L[Gm::PADN * Gm::LDMAX];
+  if (P.gate && (P.gate->done | P.gate->finishing)) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   const int b = blockIdx.x % P.nblk, co = blockIdx.x / P.nblk, c = co >> 3, o = co & 7;
@@ -455,7 +457,7 @@ void fdmo_finalize(FdmOct &O) {
   O.bxy.upload(B);
 }
 
-void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch) {
+void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch, const PcgScalars *gate) {
   static int stamp_calls = 0; const char *stamp_path = std::getenv("PORO_FDMO_STAMPS");
   const bool stamping = stamp_path && ++stamp_calls == 3;          // diagnostic: the third application of the process writes its per-block time stamps
   DevBuf<unsigned long long> stamps; std::vector<std::pair<int, int64_t>> stamp_off;
@@ -464,7 +466,7 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
   P.co_stride = O.co_stride; P.hx = hxp; P.pl = hxp * hy;
-  P.bxy = O.bxy.p;
+  P.bxy = O.bxy.p; P.gate = gate;
   for (int c = 0; c < 3; ++c) { P.cz[c] = O.coef[c][2]; for (int p = 0; p < 2; ++p) P.lam_z[c][p] = O.lam[c][2][p].p; }
   // pass 1: per z-plane, X[ky][kx] -> Fy (X Fx^T)
   P.mode = 0; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 0; P.bit2 = 1;

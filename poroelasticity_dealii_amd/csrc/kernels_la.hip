@@ -12,14 +12,22 @@
 namespace poro {
 namespace {
 
+__global__ void k_post(Mailbox *mb, unsigned long long seq, const double *src, int n, const PcgScalars *sc) {
+  if ((int)threadIdx.x < n) mb->vals[threadIdx.x] = src[threadIdx.x];
+  if (sc && threadIdx.x == 32) mb->sc = *sc;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(const_cast<unsigned long long *>(&mb->seq), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_fill(double *x, double v, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] = v;
 }
 __global__ void k_axpy(double *y, double a, const double *x, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] += a * x[i];
 }
-__global__ void k_dot(const double *a, const double *b, int64_t n, double *partials) {
+__global__ void k_dot(const double *a, const double *b, int64_t n, double *partials, const PcgScalars *gate) {
   __shared__ double sh[4];
+  if (gate && (gate->done | gate->finishing)) return;
   double s = 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) s += a[i] * b[i];
   s = block_sum(s, sh);
@@ -374,6 +382,7 @@ template <class F> void dispatch_lanes(int L, F &&f) {
 
 }  // namespace
 
+void la_post(hipStream_t s, Mailbox *mb, unsigned long long seq, const double *src, int n, const PcgScalars *sc) { hipLaunchKernelGGL(k_post, 1, 64, 0, s, mb, seq, src, n, sc); }
 void la_fill(hipStream_t s, double *x, double v, int64_t n) { if (n) hipLaunchKernelGGL(k_fill, grid_for(n), kBlock, 0, s, x, v, n); }
 void la_copy(hipStream_t s, double *y, const double *x, int64_t n) { if (n && y != x) PORO_HIP(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, s)); }
 void la_axpy(hipStream_t s, double *y, double a, const double *x, int64_t n) { if (n) hipLaunchKernelGGL(k_axpy, grid_for(n), kBlock, 0, s, y, a, x, n); }
@@ -385,8 +394,8 @@ __global__ void k_add_two_ranges(double *y0, const double *x0, double *y1, const
 void la_add_two_ranges(hipStream_t s, double *y0, const double *x0, double *y1, const double *x1, int64_t n) {
   if (n && (y0 || y1)) hipLaunchKernelGGL(k_add_two_ranges, grid_for(n), kBlock, 0, s, y0, x0, y1, x1, n);
 }
-void la_dot_partials(hipStream_t s, const double *a, const double *b, int64_t n, double *partials) {
-  hipLaunchKernelGGL(k_dot, reduce_grid(n), kBlock, 0, s, a, b, n, partials);
+void la_dot_partials(hipStream_t s, const double *a, const double *b, int64_t n, double *partials, const PcgScalars *gate) {
+  hipLaunchKernelGGL(k_dot, reduce_grid(n), kBlock, 0, s, a, b, n, partials, gate);
 }
 void la_norm_partials(hipStream_t s, const double *a, int64_t n, double *p2, double *pinf) {
   hipLaunchKernelGGL(k_norm, reduce_grid(n), kBlock, 0, s, a, n, p2, pinf);
