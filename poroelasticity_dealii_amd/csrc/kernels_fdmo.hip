@@ -220,41 +220,40 @@ template <int NT> struct PassGeom {
 // One item (= one (component, octant, block)) per workgroup; the hardware dispatcher balances the items over the CUs.
 // Workgroup shape (census of resident workgroups per CU, profiles/r03_lds_residency.txt): a 5-wave workgroup - the natural shape for 5 x 5 tiles - is given the
 // registers of an 8-wave one (two slots on every SIMD), which left 1.2-2 workgroups resident and the matrix pipe idle 55 % of the time (profiles/r03_fdmo_stamps_v1.txt).
-// 4-wave workgroups keep three resident at up to 128 registers, one wave of each on every SIMD.  So for NT = 5 FOUR waves share the 25 tiles: wave w owns tile row
-// (or column) w in full plus tile (4, w) [(w, 4)], and every wave also computes tile (4, 4), of which only the last wave's copy is used - 7 tiles per wave, no
-// branch inside the GEMM, 12 % more matrix work than the 25 tiles need.
+// 4-wave workgroups keep three resident at up to 128 registers, one wave of each on every SIMD.  So for NT = 5 FOUR waves share the tiles:
+//   passes 1 / 3 (5 x 5 tiles): wave w owns tile row (or column) w in full plus tile (4, w) [(w, 4)]; tile (4, 4) goes to the wave whose number equals the item number
+//     mod 4, so that over the items every SIMD gets the same share (6.25 tiles per wave on average; the two GEMM bodies - with and without the seventh tile - are
+//     separate branch-free instruction streams);
+//   pass 2 (lines are independent): chunks of 64 columns = 5 x 4 tiles, wave w owns (w, 0..3) and (4, w): five tiles each, nothing left over.
 template <int NT, int MODE>
 __global__ void __launch_bounds__(64 * (NT < 4 ? NT : 4))
-k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_round) {
+k_fdmo_pass(OctPass P, const double *in, double *out) {
   typedef PassGeom<NT> Gm;
   constexpr int NW = NT < 4 ? NT : 4;                        // waves
   constexpr bool EXTRA = NT > NW;                            // NT == 5: the fifth tile row / column is shared out
   constexpr int XT = NT - 1;                                 // index of that tile row / column
-  constexpr int NACC = EXTRA ? NT + 2 : NT;
+  constexpr int NL = (MODE == 1 && EXTRA) ? NW : NT;         // tiles a wave loops over beside its own (pass 2: column tiles of a chunk)
+  constexpr bool CORNER = EXTRA && MODE != 1;                // tile (XT, XT) exists
+  constexpr int NACC = NL + (EXTRA ? 1 : 0) + (CORNER ? 1 : 0);
   constexpr bool kColsFirst = MODE == 0, kColsSecond = MODE == 2;
   constexpr int LD1 = kColsFirst ? Gm::LDA : Gm::LDB, LD2 = kColsSecond ? Gm::LDA : Gm::LDB;
   constexpr int NS = EXTRA ? 2 : 1;                          // fragment streams per wave: its own tile row of T (and the shared one)
+  constexpr int PADC = 16 * NL;                              // padded block columns
   __shared__ double L[Gm::PADN * Gm::LDMAX];
   if (P.gate && (P.gate->done | P.gate->finishing)) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   const int b = blockIdx.x % P.nblk, co = blockIdx.x / P.nblk, c = co >> 3, o = co & 7;
+  const bool heavy = CORNER && w == (int)(blockIdx.x & (NW - 1));   // this wave also computes tile (XT, XT)
   const int64_t base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
   const int R = P.R, C = MODE == 1 ? min(P.C, P.pl - b * P.C) : P.C;
   const double *__restrict__ T1 = P.T1[c][(o >> P.bit1) & 1] + lane, *__restrict__ T2 = P.T2[c][(o >> P.bit2) & 1] + lane;
   auto stamp = [&](int k) { if (P.stamps && tid == 0) P.stamps[(int64_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime(); };
-  // All workgroups of the first round (three per CU) start together and would load, multiply and store in lockstep - memory and matrix phases then ADD instead of
-  // overlapping (measured: 29 us + 51 us = 82 us per pass).  The second / third workgroup of a CU therefore waits a third / two thirds of an item's lifetime.
-  if (stagger > 0 && (int)blockIdx.x < first_round) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)stagger * (((int)blockIdx.x * 3) / first_round);
-    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
   stamp(0);
-  // ---- block -> LDS, zero padded to PADN x PADN (the padding meets zero columns of T, but must be finite).  Rows are 16-byte aligned (even pitch, even chunk
+  // ---- block -> LDS, zero padded to PADN x PADC (the padding meets zero columns of T, but must be finite).  Rows are 16-byte aligned (even pitch, even chunk
   //      offsets, even C): 16-byte loads and LDS stores, all loads in flight before the first LDS store ----
-  __builtin_amdgcn_s_setprio(3);   // the few instructions of the load phase go ahead of the co-resident workgroups' matrix streams
   {
-    constexpr int HP = Gm::PADN / 2, TOT = Gm::PADN * HP, PER = (TOT + 64 * NW - 1) / (64 * NW);
+    constexpr int HP = PADC / 2, TOT = Gm::PADN * HP, PER = (TOT + 64 * NW - 1) / (64 * NW);
     double2 stage[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
@@ -266,13 +265,14 @@ k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_rou
   }
   // transform-matrix fragments in two rotating register buffers of 4 k-steps: the 2 NT chunks of the two GEMMs form one sequence, and a buffer is refilled with the
   // chunk after next as soon as the MFMAs that used it have been issued
-  double tf[2][NS][4];
-  auto load_chunk = [&](int buf, int step) {                 // step < NT: chunk `step` of T1, else chunk step - NT of T2
-    const double *__restrict__ T = step < NT ? T1 : T2; const int ch = step < NT ? step : step - NT;
+  constexpr int CHK = EXTRA ? 2 : 4, NCH = Gm::KKP / CHK;     // k-steps per chunk (two fragment streams at NT = 5: smaller chunks keep the kernel within the registers of three resident workgroups), chunks per GEMM
+  double tf[2][NS][CHK];
+  auto load_chunk = [&](int buf, int step) {                 // step < NCH: chunk `step` of T1, else chunk step - NCH of T2
+    const double *__restrict__ T = step < NCH ? T1 : T2; const int ch = step < NCH ? step : step - NCH;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      tf[buf][0][k] = T[((int64_t)w * Gm::KKP + 4 * ch + k) * 64];
-      if constexpr (EXTRA) tf[buf][1][k] = T[((int64_t)XT * Gm::KKP + 4 * ch + k) * 64];
+    for (int k = 0; k < CHK; ++k) {
+      tf[buf][0][k] = T[((int64_t)w * Gm::KKP + CHK * ch + k) * 64];
+      if constexpr (EXTRA) tf[buf][1][k] = T[((int64_t)XT * Gm::KKP + CHK * ch + k) * 64];
     }
   };
   v4d acc[NACC];
@@ -280,56 +280,55 @@ k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_rou
 #pragma unroll
     for (int t = 0; t < NACC; ++t) acc[t] = v4d{0, 0, 0, 0};
   };
-  // one GEMM = NT chunks.  Every tile of the padded problem is computed (the padding is exact zeros: no predicates inside), only whole trailing k-steps are skipped.
-  //   contract columns: acc[t] = tile (t, w) = sum_k data(rows of tile t, k) T(rows of tile w, k); extra: acc[NT] = tile (w, XT), acc[NT + 1] = tile (XT, XT)
-  //   contract rows:    acc[u] = tile (w, u) = sum_k T(rows of tile w, k) data(k, columns of tile u); extra: acc[NT] = tile (XT, w), acc[NT + 1] = tile (XT, XT)
-  auto gemm = [&](auto contract_cols, auto ld_c, auto first_step_c, int kk_n) {
-    constexpr bool kCols = decltype(contract_cols)::value; constexpr int LD = decltype(ld_c)::value, S0 = decltype(first_step_c)::value;
+  // one GEMM = NCH chunks of CHK k-steps.  Every tile of the padded problem is computed (the padding is exact zeros: no predicates inside), only whole trailing k-steps are skipped.
+  //   contract columns: acc[t] = tile (t, w) = sum_k data(rows of tile t, k) T(rows of tile w, k); extra: acc[NL] = tile (w, XT), acc[NL + 1] = tile (XT, XT)
+  //   contract rows:    acc[u] = tile (w, u) = sum_k T(rows of tile w, k) data(k, columns of tile u); extra: acc[NL] = tile (XT, w), acc[NL + 1] = tile (XT, XT)
+  auto gemm = [&](auto contract_cols, auto ld_c, auto first_step_c, auto corner_c, int kk_n) {
+    constexpr bool kCols = decltype(contract_cols)::value, kCorner = decltype(corner_c)::value; constexpr int LD = decltype(ld_c)::value, S0 = decltype(first_step_c)::value;
     const double *La = kCols ? L + j * LD + kq : L + kq * LD + j;
     const double *Lw = kCols ? La + 16 * w * LD : La + 16 * w;                 // this wave's own tile row / column of the data (runtime w)
 #pragma unroll
-    for (int ch = 0; ch < NT; ++ch) {
-      constexpr int dummy = 0; (void)dummy;
+    for (int ch = 0; ch < NCH; ++ch) {
       const int buf = (S0 + ch) & 1;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int kk = 4 * ch + k;
-        if (ch < NT - 1 || k == 0 || kk < kk_n) {            // (kk_n >= KKP - 3 always: wave-uniform branches on the last three k-steps only)
+      for (int k = 0; k < CHK; ++k) {
+        const int kk = CHK * ch + k;
+        if (kk < Gm::KKP - 3 || kk < kk_n) {                 // (kk_n >= KKP - 3 always: wave-uniform branches on the last three k-steps only)
           double d[NT];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) d[t] = kCols ? La[16 * t * LD + 4 * kk] : La[4 * kk * LD + 16 * t];
+          for (int t = 0; t < NT; ++t) if (t < NL || (kCorner && t == XT)) d[t] = kCols ? La[16 * t * LD + 4 * kk] : La[4 * kk * LD + 16 * t];
           double dw = 0; if constexpr (EXTRA) dw = kCols ? Lw[4 * kk] : Lw[4 * kk * LD];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(d[t], tf[buf][0][k], acc[t], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][0][k], d[t], acc[t], 0, 0, 0);
-          if constexpr (EXTRA) {
-            acc[NT] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(dw, tf[buf][1][k], acc[NT], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][1][k], dw, acc[NT], 0, 0, 0);
-            acc[NT + 1] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(d[XT], tf[buf][1][k], acc[NT + 1], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][1][k], d[XT], acc[NT + 1], 0, 0, 0);
-          }
+          for (int t = 0; t < NL; ++t) acc[t] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(d[t], tf[buf][0][k], acc[t], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][0][k], d[t], acc[t], 0, 0, 0);
+          if constexpr (EXTRA) acc[NL] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(dw, tf[buf][1][k], acc[NL], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][1][k], dw, acc[NL], 0, 0, 0);
+          if constexpr (kCorner) acc[NL + 1] = kCols ? __builtin_amdgcn_mfma_f64_16x16x4f64(d[XT], tf[buf][1][k], acc[NL + 1], 0, 0, 0) : __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][1][k], d[XT], acc[NL + 1], 0, 0, 0);
         }
       }
-      if (S0 + ch + 2 < 2 * NT) load_chunk(buf, S0 + ch + 2);
+      if (S0 + ch + 2 < 2 * NCH) load_chunk(buf, S0 + ch + 2);
     }
   };
-  // accumulator -> element (16 tr + 4 q + kq, 16 tc + j) of tile (tr, tc)
-  auto tile_of = [&](int a, int &tr, int &tc, bool cols) {     // which tile accumulator a holds
-    if (a < NT) { tr = cols ? a : w; tc = cols ? w : a; }
-    else if (a == NT) { tr = cols ? w : XT; tc = cols ? XT : w; }
+  // accumulator a holds tile (tr, tc): element (16 tr + 4 q + kq, 16 tc + j)
+  auto tile_of = [&](int a, int &tr, int &tc, bool cols) {
+    if (a < NL) { tr = cols ? a : w; tc = cols ? w : a; }
+    else if (a == NL) { tr = cols ? w : XT; tc = cols ? XT : w; }
     else { tr = XT; tc = XT; }
   };
   typedef std::integral_constant<bool, kColsFirst> CF; typedef std::integral_constant<int, LD1> L1c;
   typedef std::integral_constant<bool, kColsSecond> CS; typedef std::integral_constant<int, LD2> L2c;
+  typedef std::integral_constant<int, 0> S0c; typedef std::integral_constant<int, NCH> S1c;
+  __builtin_amdgcn_s_setprio(3);   // the few instructions of the load phase go ahead of the co-resident workgroups' matrix streams
   load_chunk(0, 0); load_chunk(1, 1);
   zero_acc();
   __builtin_amdgcn_s_setprio(0);
   __syncthreads();
   stamp(1);
-  gemm(CF{}, L1c{}, std::integral_constant<int, 0>{}, P.kk1);
+  if (heavy) gemm(CF{}, L1c{}, S0c{}, std::integral_constant<bool, CORNER>{}, P.kk1); else gemm(CF{}, L1c{}, S0c{}, std::false_type{}, P.kk1);
   __syncthreads();                                   // everybody has finished reading the input block
   stamp(2);
   // ---- first result -> LDS in the layout of the second GEMM (MODE 1: divided by the eigenvalue sums on the way) ----
   if constexpr (MODE == 1) {
-    // rows of this wave's tiles: tile row w (and the shared row XT); columns: tile column of the accumulator.  One accumulator at a time (sched_barrier), otherwise
-    // the eigenvalue loads of all seven pile up in registers
+    // rows of this wave's tiles: tile row w (and the shared row XT); columns: tile column of the accumulator.  One entry at a time (sched_barrier), otherwise the
+    // reciprocal sequences of all of them pile up in registers
     const double *lamz = P.lam_z[c][(o >> 2) & 1], *bx = P.bxy + (int64_t)(4 * c + (o & 3)) * P.pl;
     const double czc = P.cz[c];
     double lzw[4], lzx[4];
@@ -338,12 +337,11 @@ k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_rou
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
       int tr, tc; tile_of(a, tr, tc, false);
-      if (a == NT + 1 && w != NW - 1) continue;              // tile (XT, XT): every wave has computed it, the last one writes it
       const double bxy = bx[min(b * P.C + 16 * tc + j, P.pl - 1)];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         // reciprocal by v_rcp_f64 + one Newton step; modes that do not exist carry lam = inf and give exactly 0
-        const double den = (a < NT ? lzw[q] : lzx[q]) + bxy;
+        const double den = (a < NL ? lzw[q] : lzx[q]) + bxy;
         double r = __builtin_amdgcn_rcp(den);
         r = den < 1e300 ? fma(r, fma(-den, r, 1.0), r) : 0.0;
         L[(16 * tr + 4 * q + kq) * LD2 + 16 * tc + j] = acc[a][q] * r;
@@ -354,7 +352,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_rou
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
       int tr, tc; tile_of(a, tr, tc, kColsFirst);
-      if (a == NT + 1 && w != NW - 1) continue;
+      if (a == NL + 1 && !heavy) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) L[(16 * tr + 4 * q + kq) * LD2 + 16 * tc + j] = acc[a][q];
     }
@@ -362,13 +360,13 @@ k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_rou
   zero_acc();
   __syncthreads();
   stamp(3);
-  gemm(CS{}, L2c{}, std::integral_constant<int, NT>{}, P.kk2);
+  if (heavy) gemm(CS{}, L2c{}, S1c{}, std::integral_constant<bool, CORNER>{}, P.kk2); else gemm(CS{}, L2c{}, S1c{}, std::false_type{}, P.kk2);
   if (P.stamps) { __syncthreads(); stamp(4); }
   // ---- store ----
 #pragma unroll
   for (int a = 0; a < NACC; ++a) {
     int tr, tc; tile_of(a, tr, tc, kColsSecond);
-    if (a == NT + 1 && w != NW - 1) continue;
+    if (a == NL + 1 && !heavy) continue;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int r = 16 * tr + 4 * q + kq, cc = 16 * tc + j; if (r < R && cc < C) out[base + (int64_t)r * P.row_stride + cc] = acc[a][q]; }
   }
@@ -379,15 +377,10 @@ k_fdmo_pass(OctPass P, const double *in, double *out, int stagger, int first_rou
 }
 
 template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out) {
-  static int n_cu = 0;
-  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t prop; n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
-  // first-round stagger in 100 MHz ticks per slot; only where there is more than one round of full-size items
-  static const int stagger = std::getenv("PORO_FDMO_STAGGER") ? std::atoi(std::getenv("PORO_FDMO_STAGGER")) : 800;
-  const int first_round = std::min(n_items, 3 * n_cu), stg = (NT == 5 && n_items > 3 * n_cu) ? stagger : 0;
   const dim3 grid((unsigned)n_items), block(64 * (NT < 4 ? NT : 4));
-  if (P.mode == 0) hipLaunchKernelGGL((k_fdmo_pass<NT, 0>), grid, block, 0, s, P, in, out, stg, first_round);
-  else if (P.mode == 1) hipLaunchKernelGGL((k_fdmo_pass<NT, 1>), grid, block, 0, s, P, in, out, stg, first_round);
-  else hipLaunchKernelGGL((k_fdmo_pass<NT, 2>), grid, block, 0, s, P, in, out, stg, first_round);
+  if (P.mode == 0) hipLaunchKernelGGL((k_fdmo_pass<NT, 0>), grid, block, 0, s, P, in, out);
+  else if (P.mode == 1) hipLaunchKernelGGL((k_fdmo_pass<NT, 1>), grid, block, 0, s, P, in, out);
+  else hipLaunchKernelGGL((k_fdmo_pass<NT, 2>), grid, block, 0, s, P, in, out);
 }
 void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const double *in, double *out) {
   switch (nt) {
@@ -471,11 +464,12 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
   // pass 1: per z-plane, X[ky][kx] -> Fy (X Fx^T)
   P.mode = 0; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 0; P.bit2 = 1;
   for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][0][p].p; P.T2[c][p] = O.fwd[c][1][p].p; }
-  if (stamping) { stamps.alloc((size_t)8 * 24 * (O.h[2] + (hxp * hy + 16 * nt - 1) / (16 * nt) + O.h[2])); stamps.zero(s); }
+  if (stamping) { stamps.alloc((size_t)8 * 24 * (O.h[2] + (hxp * hy + 16 * std::min(nt, 4) - 1) / (16 * std::min(nt, 4)) + O.h[2])); stamps.zero(s); }
   P.stamps = stamping ? stamps.p : nullptr; stamp_off.push_back({24 * P.nblk, 0});
   launch_pass_nt(s, nt, P, 24 * P.nblk, g_oct, scratch);
   // pass 2: per chunk of 16 NT columns of a (component, octant) block, X[kz][col] -> Bz scale (Fz X), in place
-  P.mode = 1; P.R = hz; P.C = 16 * nt; P.nt_r = tiles(hz); P.nt_c = nt; P.kk1 = ksteps(hz); P.kk2 = ksteps(hz); P.nblk = (hxp * hy + 16 * nt - 1) / (16 * nt); P.blk_stride = 16 * nt; P.row_stride = (int64_t)hxp * hy; P.bit1 = 2; P.bit2 = 2;
+  const int cw = 16 * std::min(nt, 4);            // chunk width of pass 2: 5 x 4 tiles for the four waves of an NT = 5 workgroup
+  P.mode = 1; P.R = hz; P.C = cw; P.nt_r = tiles(hz); P.nt_c = cw / 16; P.kk1 = ksteps(hz); P.kk2 = ksteps(hz); P.nblk = (hxp * hy + cw - 1) / cw; P.blk_stride = cw; P.row_stride = (int64_t)hxp * hy; P.bit1 = 2; P.bit2 = 2;
   for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][2][p].p; P.T2[c][p] = O.bwd[c][2][p].p; }
   if (stamping) P.stamps = stamps.p + 8 * (int64_t)(24 * hz); stamp_off.push_back({24 * P.nblk, 8 * (int64_t)(24 * hz)});
   launch_pass_nt(s, nt, P, 24 * P.nblk, scratch, scratch);
