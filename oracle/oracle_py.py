@@ -60,6 +60,8 @@ def load():
         L.oracle_set_stop_rule.restype = None
         L.oracle_work_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
         L.oracle_work_counts.restype = None
+        L.oracle_last_run_split.argtypes = [C.c_void_p, C.POINTER(C.c_int64), _dp]
+        L.oracle_last_run_split.restype = None
         L.oracle_export_csr_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.oracle_export_csr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), _ip, _dp]
         L.oracle_apply_operator.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
@@ -161,6 +163,16 @@ class Oracle:
         out = (C.c_int64 * 6)()
         self.L.oracle_work_counts(self.ptr, out, int(reset))
         return dict(zip(("apply_u", "apply_p", "asm_rhs_u", "residual_p", "jacobian_p", "proj_rhs"), list(out)))
+
+    def last_run_split(self):
+        """(work counters at the end of the last run()'s initialisation, seconds of the initialisation, seconds of its time steps)"""
+        w, t = (C.c_int64 * 6)(), (C.c_double * 2)()
+        self.L.oracle_last_run_split(self.ptr, w, t)
+        return dict(zip(("apply_u", "apply_p", "asm_rhs_u", "residual_p", "jacobian_p", "proj_rhs"), list(w))), t[0], t[1]
+
+    def fill_synthetic_matrix(self):
+        """benchmark helper: SPD values on the real pattern of A_u (see oracle_fill_synthetic_matrix)"""
+        assert self.L.oracle_fill_synthetic_matrix(self.ptr) == 0
 
     def bench_spmv_threads(self, threads, reps=20):
         """(seconds per CSR SpMV of A_u, seconds per Jacobi-CG iteration) with the rows split over `threads` host threads"""

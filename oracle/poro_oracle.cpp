@@ -292,7 +292,8 @@ struct Oracle {
   Csr Pm; std::vector<Vec> proj_rhs, strains;
   Vec eps_v, eps_v0;
   int tensor_to_entry[9];
-  int64_t work[6] = {0, 0, 0, 0, 0, 0};   // apply_u, apply_p, asm_rhs_u, residual_p, jacobian_p, proj_rhs (same units as the host driver's counters)
+  int64_t work[6] = {0, 0, 0, 0, 0, 0};
+  int64_t work_init[6] = {0, 0, 0, 0, 0, 0}; double seconds_init = 0, seconds_steps = 0;   // oracle_run: work counters and wall time of the initialisation (:308-317) / of the time steps   // apply_u, apply_p, asm_rhs_u, residual_p, jacobian_p, proj_rhs (same units as the host driver's counters)
   Cons cons_u, cons_p;      // hanging-node constraints of the two spaces (empty on uniform meshes)
   std::vector<char> is_pdir; Vec pdir_val; bool any_pdir = false;   // EXTENSION (not in the reference): prescribed pressures, e.g. a drained boundary (include/poroel_hip.h)
   int stop_rule_u = 0;      // stopping rule of the displacement solve (see cg)
@@ -702,6 +703,13 @@ int oracle_apply_operator(oracle_ctx *c, int which, const double *x, double *y) 
 // "All host cores" context figure for the CPU baseline: CSR SpMV of the assembled A_u and Jacobi-CG iterations on it, rows split
 // over `threads` std::threads (the reference itself is serial; this is not its algorithm, only what the same data structure gives on
 // every core of the box).  out = {seconds per SpMV, seconds per CG iteration}.
+// benchmark helper: synthetic symmetric, strictly diagonally dominant (hence SPD) values on the REAL sparsity pattern of A_u, so that the threaded SpMV / CG timings below can
+// be taken at sizes whose assembly by the reference's serial cell loop would take minutes (throughput of a CSR SpMV depends on the pattern, not on the values)
+int oracle_fill_synthetic_matrix(oracle_ctx *c) {
+  Oracle *o = reinterpret_cast<Oracle *>(c); Csr &A = o->A;
+  for (int64_t r = 0; r < A.n; ++r) for (int64_t j = A.rp[r]; j < A.rp[r + 1]; ++j) A.val[j] = A.col[j] == r ? (double)(A.rp[r + 1] - A.rp[r]) : -0.5;
+  return 0;
+}
 int oracle_bench_spmv_threads(oracle_ctx *c, int threads, int reps, double *out) {
   Oracle *o = reinterpret_cast<Oracle *>(c); const Csr &A = o->A; const int64_t n = A.n;
   if (n == 0 || threads < 1 || reps < 1) return -1;
@@ -778,7 +786,7 @@ int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_
   o->stop_rule_u = (coupled_fss & 4) ? 1 : 0;
   const int dim = o->dim; int rows = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double tph[4] = {0, 0, 0, 0};
+  double tph[4] = {0, 0, 0, 0}; const double t_run0 = now();
   std::vector<int32_t> vol(dim); for (int a = 0; a < dim; ++a) vol[a] = a * dim + a;   // strain_tensor_volumetric_components PoroelasticityFSS.h:99-114
   const double om_u = prec == ORACLE_PREC_SSOR ? 1.2 : 1.0;
   auto normal_strains = [&] {                                      // get_normal_strain_components :153-164
@@ -799,6 +807,7 @@ int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_
   normal_strains();                                                // :315
   o->get_volumetric_strain(); o->eps_v0 = o->eps_v;                // :316-317
   if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = 0; r[5] = 0; r[6] = su.iterations; r[7] = 0; }
+  std::copy(o->work, o->work + 6, o->work_init); o->seconds_init = now() - t_run0; const double t_steps0 = now();
   for (int step = 1; step <= n_steps; ++step) {                    // :327 (AMR branch :333-340 out of scope)
     o->p_old = o->p;                                               // :342
     if ((coupled_fss & 2) && step > 1) o->eps_v0 = o->eps_v;       // corrected storage term: alpha (eps_v^{n+1} - eps_v^n) / dt
@@ -828,8 +837,11 @@ int oracle_run(oracle_ctx *c, double p_init, double dt, int n_steps, double fss_
       if (rows < max_rows) { double *r = trace + 8 * rows++; r[0] = step; r[1] = fss; r[2] = pit - 1; r[3] = inner_err; r[4] = pinf; r[5] = pressure_error; r[6] = su.iterations; r[7] = pcg; }
     }
   }
+  o->seconds_steps = now() - t_steps0;
   if (seconds_per_phase) std::copy(tph, tph + 4, seconds_per_phase);
   return rows;
 }
+// split of the last oracle_run: work counters at the end of the initialisation, wall seconds of the initialisation and of the time steps
+void oracle_last_run_split(oracle_ctx *c, int64_t *work_init, double *seconds /*[2]*/) { Oracle *o = reinterpret_cast<Oracle *>(c); std::copy(o->work_init, o->work_init + 6, work_init); seconds[0] = o->seconds_init; seconds[1] = o->seconds_steps; }
 
 }  // extern "C"

@@ -329,7 +329,7 @@ void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t 
 // half-size transforms of (component, direction) from the generalised eigenvectors S (nn x nn row-major, every mode symmetric or antisymmetric) and eigenvalues lam
 bool fdmo_upload_dir(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn);
 void fdmo_finalize(FdmOct &O);   // after every (component, direction) has been uploaded: derived tables
-void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch_oct, const PcgScalars *gate = nullptr);   // z = blockdiag(A_cc)^-1 g, all in octant form; gate: no-op once gate->done / finishing
+void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch_oct, const PcgScalars *gate = nullptr, hipEvent_t *ev /* optional: 3 start / stop pairs attached to the three pass dispatches */ = nullptr);   // z = blockdiag(A_cc)^-1 g, all in octant form; gate: no-op once gate->done / finishing
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v_nodal, double *q_oct);   // q = H v (node-interleaved vector -> octant form)
 void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r_oct, double *v_nodal);     // v = H^-1-form of the backward transform: v_k = a + b, v_k' = a - b
 // the vector kernels of pcg() with g / z in octant form (same device-side scalar protocol as their nodal counterparts in kernels_la.hip)

@@ -436,7 +436,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   // the extrapolation must not run away after an atypical solve (a warm restart that took 3 iterations, followed by a real step): never expect more than a quarter
   // above the last count, and nothing above it where an overshoot is expensive
   if (expect > 0) expect = std::min(expect, cheap_overshoot ? its_hint[0] + std::max(2, its_hint[0] / 4) : its_hint[0]);
-  int batch = expect > 0 ? (cheap_overshoot ? std::min(expect, 256) : std::max(1, expect - 1)) : (precond ? 1 : 4);   // (a repeated step hits `expect` exactly: no launch behind the end)
+  int batch = expect > 0 ? (cheap_overshoot ? std::min(expect, 256) : std::max(1, expect - 1)) : (precond && !cheap_overshoot ? 1 : 4);   // no history: a poll (~15 us through the mailbox) every 4 iterations
   while (true) {
     for (int k = 0; k < batch; ++k) {
       ++it;
@@ -455,6 +455,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
     post_and_wait(c, nullptr, 0, sc); hs = c->mailbox->sc;
     if (hs.done || hs.finishing) break;
     if (expect > 0) batch = cheap_overshoot ? 3 : 1;
+    else if (cheap_overshoot && precond) batch = 4;          // (an explicit preconditioner: a no-op iteration still costs ~8 launches)
     else if (batch < 32) batch *= 2;
   }
   if (its_hint) { its_hint[1] = its_hint[0]; its_hint[0] = hs.it; }
@@ -1187,6 +1188,8 @@ int poro_state_restore(poro_ctx *c) {
     PORO_HIP(hipSetDevice(c->device));
     if (c->vec_saved.empty()) throw Error("state_restore without state_save");
     for (auto &kv : c->vec_saved) la_copy(c->stream, c->vec.at(kv.first).p, kv.second.p, (int64_t)kv.second.n);
+    // the solves that follow repeat earlier ones: forget the iteration-count history, so that a measurement of a repeated step cannot profit from a perfect prediction
+    for (int *h : {c->pcg_hint_u, c->pcg_hint_fdm_u, c->pcg_hint_cheb_u}) h[0] = h[1] = 0;
     return 0;
   });
 }
@@ -1457,7 +1460,17 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *in_iteration) {
         // g, z in octant form: three contiguous sweeps; inside the iteration the launches are gated on the device-side "solve finished" flag (before
         // pcg_scalars_start it still holds the previous solve's state)
-        if (oct) { Timed tm(c, "precondition_u_fdm"); fdmo_apply(c->stream, *oct, g, z, c->fdm_oct.t.p, in_iteration ? c->scal.p : nullptr); }
+        if (oct) {
+          Timed tm(c, "precondition_u_fdm");
+          if (c->timing && c->timers["fdm_u_pass1"].sample(c->timing_stride)) {     // the three transform dispatches individually (per-kernel roofline of the bench)
+            c->timers["fdm_u_pass2"].enqueued++; c->timers["fdm_u_pass3"].enqueued++;
+            isolate_sampled_dispatch(c);
+            hipEvent_t ev[6]; for (auto &e : ev) e = event_get(c);
+            fdmo_apply(c->stream, *oct, g, z, c->fdm_oct.t.p, in_iteration ? c->scal.p : nullptr, ev);
+            const char *names[3] = {"fdm_u_pass1", "fdm_u_pass2", "fdm_u_pass3"};
+            for (int k = 0; k < 3; ++k) { Timer &t = c->timers[names[k]]; t.pending.emplace_back(ev[2 * k], ev[2 * k + 1]); t.launches++; }
+          } else fdmo_apply(c->stream, *oct, g, z, c->fdm_oct.t.p, in_iteration ? c->scal.p : nullptr);
+        }
         else fdm_precondition_u(c, g, z);
         return false; };
       DiagVec dz; dz.full = c->dinv_u.p; dz.ncomp = c->dim; dz.inert = c->dir_mask.p; dz.z = c->wz_u.p;

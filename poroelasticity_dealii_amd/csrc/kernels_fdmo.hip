@@ -22,6 +22,7 @@
 // register q of lane j + 16 kq, so one store routine serves both.
 #include "common.hpp"
 #include "device_reduce.hpp"
+#include <hip/hip_ext.h>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -376,19 +377,20 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   }
 }
 
-template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out) {
+template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid((unsigned)n_items), block(64 * (NT < 4 ? NT : 4));
-  if (P.mode == 0) hipLaunchKernelGGL((k_fdmo_pass<NT, 0>), grid, block, 0, s, P, in, out);
-  else if (P.mode == 1) hipLaunchKernelGGL((k_fdmo_pass<NT, 1>), grid, block, 0, s, P, in, out);
-  else hipLaunchKernelGGL((k_fdmo_pass<NT, 2>), grid, block, 0, s, P, in, out);
+  // (events attached to the dispatch itself: the kernel's own duration, as rocprofv3 reports it)
+  if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0>), grid, block, 0, s, e0, e1, 0, P, in, out);
+  else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1>), grid, block, 0, s, e0, e1, 0, P, in, out);
+  else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2>), grid, block, 0, s, e0, e1, 0, P, in, out);
 }
-void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const double *in, double *out) {
+void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const double *in, double *out, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   switch (nt) {
-    case 1: launch_pass<1>(s, P, n_blocks, in, out); break;
-    case 2: launch_pass<2>(s, P, n_blocks, in, out); break;
-    case 3: launch_pass<3>(s, P, n_blocks, in, out); break;
-    case 4: launch_pass<4>(s, P, n_blocks, in, out); break;
-    case 5: launch_pass<5>(s, P, n_blocks, in, out); break;
+    case 1: launch_pass<1>(s, P, n_blocks, in, out, e0, e1); break;
+    case 2: launch_pass<2>(s, P, n_blocks, in, out, e0, e1); break;
+    case 3: launch_pass<3>(s, P, n_blocks, in, out, e0, e1); break;
+    case 4: launch_pass<4>(s, P, n_blocks, in, out, e0, e1); break;
+    case 5: launch_pass<5>(s, P, n_blocks, in, out, e0, e1); break;
     default: throw Error("fdmo: half lines of more than 80 entries");
   }
 }
@@ -450,7 +452,7 @@ void fdmo_finalize(FdmOct &O) {
   O.bxy.upload(B);
 }
 
-void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch, const PcgScalars *gate) {
+void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch, const PcgScalars *gate, hipEvent_t *ev) {
   static int stamp_calls = 0; const char *stamp_path = std::getenv("PORO_FDMO_STAMPS");
   const bool stamping = stamp_path && ++stamp_calls == 3;          // diagnostic: the third application of the process writes its per-block time stamps
   DevBuf<unsigned long long> stamps; std::vector<std::pair<int, int64_t>> stamp_off;
@@ -466,18 +468,18 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
   for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][0][p].p; P.T2[c][p] = O.fwd[c][1][p].p; }
   if (stamping) { stamps.alloc((size_t)8 * 24 * (O.h[2] + (hxp * hy + 16 * std::min(nt, 4) - 1) / (16 * std::min(nt, 4)) + O.h[2])); stamps.zero(s); }
   P.stamps = stamping ? stamps.p : nullptr; stamp_off.push_back({24 * P.nblk, 0});
-  launch_pass_nt(s, nt, P, 24 * P.nblk, g_oct, scratch);
+  launch_pass_nt(s, nt, P, 24 * P.nblk, g_oct, scratch, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
   // pass 2: per chunk of 16 NT columns of a (component, octant) block, X[kz][col] -> Bz scale (Fz X), in place
   const int cw = 16 * std::min(nt, 4);            // chunk width of pass 2: 5 x 4 tiles for the four waves of an NT = 5 workgroup
   P.mode = 1; P.R = hz; P.C = cw; P.nt_r = tiles(hz); P.nt_c = cw / 16; P.kk1 = ksteps(hz); P.kk2 = ksteps(hz); P.nblk = (hxp * hy + cw - 1) / cw; P.blk_stride = cw; P.row_stride = (int64_t)hxp * hy; P.bit1 = 2; P.bit2 = 2;
   for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][2][p].p; P.T2[c][p] = O.bwd[c][2][p].p; }
   if (stamping) P.stamps = stamps.p + 8 * (int64_t)(24 * hz); stamp_off.push_back({24 * P.nblk, 8 * (int64_t)(24 * hz)});
-  launch_pass_nt(s, nt, P, 24 * P.nblk, scratch, scratch);
+  launch_pass_nt(s, nt, P, 24 * P.nblk, scratch, scratch, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
   // pass 3: per z-plane, X[my][mx] -> (By X) Bx^T
   P.mode = 2; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hy); P.kk2 = ksteps(hx); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 1; P.bit2 = 0;
   for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.bwd[c][1][p].p; P.T2[c][p] = O.bwd[c][0][p].p; }
   if (stamping) P.stamps = stamps.p + 8 * (int64_t)(24 * hz + stamp_off[1].first); stamp_off.push_back({24 * P.nblk, 8 * (int64_t)(24 * hz + stamp_off[1].first)});
-  launch_pass_nt(s, nt, P, 24 * P.nblk, scratch, z_oct);
+  launch_pass_nt(s, nt, P, 24 * P.nblk, scratch, z_oct, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
   if (stamping) {
     PORO_HIP(hipStreamSynchronize(s));
     std::vector<unsigned long long> h(stamps.n); PORO_HIP(hipMemcpy(h.data(), stamps.p, stamps.n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
