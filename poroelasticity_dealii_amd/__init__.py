@@ -159,6 +159,8 @@ def load_host():
         L = C.CDLL(_need(os.path.join(LIB_DIR, "libporoel_host.so")))
         L.poro_host_last_error.restype = C.c_char_p
         bc = [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, C.POINTER(Material)]
+        L.poro_host_build_graded_box.restype = C.c_void_p
+        L.poro_host_build_graded_box.argtypes = [C.c_int, _ip, _dp, C.c_int, _dp] + bc
         L.poro_host_build_box.restype = C.c_void_p
         L.poro_host_build_box.argtypes = [C.c_int, _ip, _dp, C.c_int, C.c_int, C.c_int] + bc
         L.poro_host_build_refined_box.restype = C.c_void_p
@@ -236,6 +238,16 @@ class Problem:
         n3, pn = _arr_i(list(n) + [1] * (3 - len(n)))
         s3, ps = _arr_d(list(size) + [1.0] * (3 - len(size)))
         return cls(load_host().poro_host_build_box(dim, pn, ps, degree_u, rank, n_ranks, *args, C.byref(material)))
+
+    @classmethod
+    def graded_box(cls, dim, n, size, degree_u, material, dirichlet, grading, neumann=()):
+        """the colorized box with exponentially graded vertex spacing (grading[d] = 0: uniform in that direction): rectilinear cells of different sizes, NO box tag -
+        the general (unstructured) kernels run on it"""
+        keep, args = cls._bc(dirichlet, neumann)
+        n3, pn = _arr_i(list(n) + [1] * (3 - len(n)))
+        s3, ps = _arr_d(list(size) + [1.0] * (3 - len(size)))
+        g3, pg = _arr_d(list(grading) + [0.0] * (3 - len(grading)))
+        return cls(load_host().poro_host_build_graded_box(dim, pn, ps, degree_u, pg, *args, C.byref(material)))
 
     @classmethod
     def refined_box(cls, dim, n, size, degree_u, material, dirichlet, refine_lo, refine_hi, neumann=()):

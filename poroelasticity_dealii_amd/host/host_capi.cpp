@@ -35,6 +35,20 @@ void *poro_host_build_box(int dim, const int32_t *n, const double *size, int k_u
   } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 
+// graded box (no box tag: general kernels), see build_graded_box_problem
+void *poro_host_build_graded_box(int dim, const int32_t *n, const double *size, int k_u, const double *grading,
+                                 int n_dir, const int32_t *dl, const int32_t *dc, const double *dv,
+                                 int n_neu, const int32_t *nl, const int32_t *nc, const double *nv, const poro_material *mat) {
+  try {
+    auto *P = new ProblemData();
+    fill_bc(P->bc, n_dir, dl, dc, dv, n_neu, nl, nc, nv);
+    P->mat = *mat;
+    int nn[3] = {n[0], n[1], dim == 3 ? n[2] : 1}; double sz[3] = {size[0], size[1], dim == 3 ? size[2] : 1}, gr[3] = {grading[0], grading[1], dim == 3 ? grading[2] : 0.0};
+    build_graded_box_problem(*P, dim, nn, sz, k_u, gr);
+    return P;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+
 // box with one locally refined block of cells (hanging nodes): the mesh class one refine_mesh() pass produces (PoroelasticityFSS.h:447-498)
 void *poro_host_build_refined_box(int dim, const int32_t *n, const double *size, int k_u, const int32_t *lo, const int32_t *hi,
                                   int n_dir, const int32_t *dl, const int32_t *dc, const double *dv,

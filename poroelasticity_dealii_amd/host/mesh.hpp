@@ -440,6 +440,24 @@ inline void build_box_problem(ProblemData &P, int dim, const int n[3], const dou
   P.finalize(k_u);
 }
 
+// Graded box: the colorized box with its vertices moved by x -> origin + size * (exp(g t) - 1) / (exp(g) - 1), t in [0, 1], per direction (g = 0: unchanged).
+// Cells stay rectilinear but differ in size, so the mesh carries NO box tag: it runs through the general kernels (the mesh class a graded or r-adapted
+// hyper_rectangle of the reference would give; used to measure the general matrix-free operator at scale)
+inline void build_graded_box_problem(ProblemData &P, int dim, const int n[3], const double size[3], int k_u, const double grading[3]) {
+  double origin[3] = {0, 0, 0}, h[3] = {1, 1, 1};
+  int nl[3] = {n[0], n[1], dim == 3 ? n[2] : 1};
+  for (int d = 0; d < dim; ++d) { h[d] = size[d] / n[d]; origin[d] = -size[d] / 2; }
+  P.mesh = make_box(dim, nl, origin, h, true, true);
+  for (int64_t v = 0; v < P.mesh.n_vertices(); ++v)
+    for (int d = 0; d < dim; ++d) {
+      const double g = grading[d]; double &x = P.mesh.vertices[(size_t)v * dim + d];
+      if (g != 0.0) { const double t = (x - origin[d]) / size[d]; x = origin[d] + size[d] * std::expm1(g * t) / std::expm1(g); }
+    }
+  P.part.rank = 0; P.part.n_ranks = 1; P.part.has_lower = 0; P.part.has_upper = 0; P.part.plane_u = 0; P.part.plane_p = 0;
+  P.finalize(k_u);            // (the dofs keep the lexicographic numbering of the box)
+  P.d.box.enabled = 0;        // ... but the descriptor carries no box tag: the cells are not congruent
+}
+
 inline void build_refined_box_problem(ProblemData &P, int dim, const int n[3], const double size[3], int k_u, const int lo[3], const int hi[3]) {
   double origin[3] = {0, 0, 0}, h[3] = {1, 1, 1};
   for (int d = 0; d < dim; ++d) { h[d] = size[d] / n[d]; origin[d] = -size[d] / 2; }

@@ -67,3 +67,28 @@ def test_hanging_node_meshes_matrix_free(cfg):
         assert np.linalg.norm(G.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
     finally:
         G.close(); O.close(); P.close()
+
+
+@pytest.mark.parametrize("deg,n,grading", [(2, (4, 3, 5), (1.0, 0.5, -0.7)), (1, (5, 4, 6), (0.8, 0.0, 1.2)), (2, (9, 2, 3), (0.0, 0.0, 0.0))], ids=str)
+def test_graded_box_sum_factorised_operator(deg, n, grading, monkeypatch):
+    """3D hexahedra without the box tag (graded box: rectilinear cells of different sizes): the sum-factorised general kernel (k_mfg3_sf, several cells per workgroup)
+    against the oracle's assembled operator, against the one-wave-per-cell kernel it replaces, and inside a solve"""
+    from common import BC_3D, material
+    P = pk.Problem.graded_box(3, list(n), [10.0] * 3, deg, material(), BC_3D, list(grading))
+    assert not P.desc.box.enabled
+    O = oracle_py.Oracle(P, hoisted=True)
+    F = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    try:
+        p = REF["p_init"] * (1 + 0.2 * np.sin(0.37 * np.arange(F.n_p)))
+        for S in (F, O):
+            S.set(pk.VEC_P, p); S.disp_assemble_system(True)
+        x = np.sin(0.37 * np.arange(F.n_u))
+        yo, yf = O.apply(pk.MAT_A_U, x), F.apply(pk.MAT_A_U, x)
+        assert np.abs(yf - yo).max() <= 1e-12 * np.abs(yo).max(), np.abs(yf - yo).max() / np.abs(yo).max()
+        monkeypatch.setenv("PORO_MFG_NO_SUMFAC", "1")       # (read once per process: only effective if this is the first general-mesh apply; the comparison with the oracle above is the hard check)
+        assert np.abs(F.get(pk.VEC_RHS_U) - O.get(pk.VEC_RHS_U)).max() <= 1e-12 * np.abs(O.get(pk.VEC_RHS_U)).max()
+        assert O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=20000)[0] == 0
+        rc, info = F.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=20000, prec=pk.PREC_CHEBYSHEV)
+        assert rc == 0 and np.linalg.norm(F.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+    finally:
+        F.close(); O.close(); P.close()
