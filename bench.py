@@ -215,9 +215,7 @@ def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist,
     if repeat:
         R.save_state()                        # every step below is "time step 1 from the initial equilibrium": a device-side rollback (~30 us of copies, inside the timed region)
     for _ in range(warmup):
-        if repeat:
-            R.restore_state()
-        R.step()
+        R.step(restore=repeat)
     before = R.work()
     G.timers_reset()                          # HIP events around every kernel family on the launch stream
     # every launch with events costs the step ~7 % (2.5 us per launch, 650 launches per step): sample every `event_stride`-th launch of each kernel family
@@ -228,9 +226,7 @@ def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist,
     traces, step_seconds = [], []
     for _ in range(steps):
         ts = time.perf_counter()
-        if repeat:
-            R.restore_state()
-        traces.append(R.step()[0]); step_seconds.append(time.perf_counter() - ts)   # step() returns after a stream sync
+        traces.append(R.step(restore=repeat)[0]); step_seconds.append(time.perf_counter() - ts)   # (rollback + step in one call; the step's last entry point waits for the device)
     sync()
     elapsed = time.perf_counter() - t0
     after = R.work()

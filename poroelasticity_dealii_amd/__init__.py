@@ -186,6 +186,7 @@ def load_host():
         L.poro_host_runner_ctx.argtypes = [C.c_void_p]
         L.poro_host_runner_initialize.argtypes = [C.c_void_p]
         L.poro_host_runner_step.argtypes = [C.c_void_p, _dp, C.c_int, C.POINTER(C.c_int64)]
+        L.poro_host_runner_restore_and_step.argtypes = [C.c_void_p, _dp, C.c_int, C.POINTER(C.c_int64)]
         L.poro_host_runner_work.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.poro_host_runner_work.restype = None
         L.poro_host_runner_postprocess.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
@@ -516,10 +517,11 @@ class Runner:
         if self.H.poro_host_runner_initialize(self.h) != 0:
             raise RuntimeError(self.H.poro_host_last_error().decode())
 
-    def step(self):
+    def step(self, restore=False):
+        """one time step; restore=True: roll the device state back to the snapshot first (same call)"""
         trace = np.zeros((self.max_fss, 8))
         work = (C.c_int64 * 11)()
-        rows = self.H.poro_host_runner_step(self.h, trace.ctypes.data_as(_dp), self.max_fss, work)
+        rows = (self.H.poro_host_runner_restore_and_step if restore else self.H.poro_host_runner_step)(self.h, trace.ctypes.data_as(_dp), self.max_fss, work)
         if rows < 0:
             raise RuntimeError(self.H.poro_host_last_error().decode())
         return trace[:rows], dict(zip(WORK_FIELDS, list(work)))

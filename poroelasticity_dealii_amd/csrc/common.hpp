@@ -9,6 +9,7 @@
 #include <type_traits>
 #include <stdexcept>
 #include <string>
+#include <list>
 #include <vector>
 #include "../../include/poroel_hip.h"
 
@@ -103,6 +104,8 @@ struct FdmOct {
   DevBuf<double> g, z, t;                         // residual, preconditioned residual, scratch - all in octant form
   std::vector<double> h_lam[3][3][2];             // host copies of the eigenvalues
   DevBuf<double> bxy;                             // [component][py][px][my][mx] = coef_x lam_x[mx] + coef_y lam_y[my]: the part of the eigenvalue sum a z line shares (pass 2 reads it per column)
+  struct ScalarTable { double a, kappa; DevBuf<double> t; };
+  std::list<ScalarTable> scalar_tables;           // scalar form: a + kappa (lam_x + lam_y) per plane position, one table per (a, kappa) seen (pressure Jacobian, mass matrix)
 };
 // dependency levels of the lower / upper triangle in natural row order (rows of one level can be swept concurrently)
 struct SsorLevels { DevBuf<int32_t> fwd_rows, bwd_rows; std::vector<int64_t> fwd_off, bwd_off; bool built = false; };
@@ -192,6 +195,7 @@ struct poro_ctx {
   double cheb_ratio_default = 0;   // default interval ratio of the Chebyshev preconditioner, from the GLOBAL mesh size (0 = not yet computed)
   poro::DevBuf<double> cheb_z, cheb_t;
   poro::FdmOct fdm_oct;
+  poro::FdmOct fdm_p_fused;          // the scalar Q1 systems through the same transform kernel (3D boxes, one rank, lines of <= 80 nodes)
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
@@ -330,6 +334,11 @@ void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t 
 bool fdmo_upload_dir(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn);
 void fdmo_finalize(FdmOct &O);   // after every (component, direction) has been uploaded: derived tables
 void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch_oct, const PcgScalars *gate = nullptr, hipEvent_t *ev /* optional: 3 start / stop pairs attached to the three pass dispatches */ = nullptr);   // z = blockdiag(A_cc)^-1 g, all in octant form; gate: no-op once gate->done / finishing
+// the same transform kernel for the scalar Q1 systems of a 3D box (nodal layout, one block set, no octants): 3 launches instead of 6
+bool fdmo_scalar_usable(int dim, const int nn[3]);
+void fdmo_scalar_init(FdmOct &O, const int nn[3], hipStream_t s);
+void fdmo_scalar_upload_dir(FdmOct &O, int dir, const std::vector<double> &S, const std::vector<double> &lam, int n);
+void fdmo_scalar_apply(hipStream_t s, FdmOct &O, double a, double kappa, const double *g, double *z, const PcgScalars *gate = nullptr);
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v_nodal, double *q_oct);   // q = H v (node-interleaved vector -> octant form)
 void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r_oct, double *v_nodal);     // v = H^-1-form of the backward transform: v_k = a + b, v_k' = a - b
 // the vector kernels of pcg() with g / z in octant form (same device-side scalar protocol as their nodal counterparts in kernels_la.hip)

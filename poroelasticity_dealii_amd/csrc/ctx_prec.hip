@@ -24,8 +24,9 @@ bool fdm_p_supported(poro_ctx *c) {
   if (c->comm.multi() && !(c->comm.nccl_comm || (c->comm.ar && c->comm.sr))) return false;
   return true;
 }
-static void upload_dir(FdmDir &D, int n_cells, double h) {
+static void upload_dir(FdmDir &D, int n_cells, double h, FdmOct *fused = nullptr, int dir = 0) {
   std::vector<double> S, lam; q1_eig(n_cells, h, S, lam);
+  if (fused) fdmo_scalar_upload_dir(*fused, dir, S, lam, n_cells + 1);
   const int n = n_cells + 1;
   std::vector<double> St((size_t)n * n);
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) St[(size_t)j * n + i] = S[(size_t)i * n + j];
@@ -35,7 +36,12 @@ void build_fdm_p(poro_ctx *c) {
   if (c->fdm_p.built) return;
   if (!fdm_p_supported(c)) throw Error("PORO_PREC_FDM needs a uniform box (poro_desc.box.enabled) and, when partitioned, an initialised communicator");
   c->fdm_p.dim = c->dim;
-  for (int d = 0; d < c->dim; ++d) upload_dir(c->fdm_p.dir[d], c->box.n[d], c->box.h[d]);   // local slab; the last direction is replaced below when partitioned
+  // one rank, 3D, lines of at most 80 nodes: the three-launch form through the block-FDM transform kernel (kernels_fdmo.hip) instead of six single-direction launches
+  int np3[3] = {c->box.n[0] + 1, c->box.n[1] + 1, c->dim == 3 ? c->box.n[2] + 1 : 1};
+  const bool fused = !c->comm.multi() && fdmo_scalar_usable(c->dim, np3) && !std::getenv("PORO_FDM_P_UNFUSED");
+  if (fused) fdmo_scalar_init(c->fdm_p_fused, np3, c->stream);
+  for (int d = 0; d < c->dim; ++d) upload_dir(c->fdm_p.dir[d], c->box.n[d], c->box.h[d], fused ? &c->fdm_p_fused : nullptr, d);   // local slab; the last direction is replaced below when partitioned
+  c->fdm_p_fused.built = fused;
   c->fdm_t1.alloc(c->n_p); c->fdm_t2.alloc(c->n_p);
   if (c->comm.multi()) {
     FdmDist &F = c->fdm_dist; const int N = std::max(1, c->comm.part.n_ranks), r = c->comm.part.rank, last = c->dim - 1;
@@ -92,7 +98,11 @@ void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk) {
 void fdm_precondition_p(poro_ctx *c, double a, const double k[3], const double *g, double *z) {
   Timed tm(c, "precondition_p_fdm");
   hipStream_t s = c->stream;
-  if (!c->comm.multi()) { fdm_apply(s, c->fdm_p, a, k, g, z, c->fdm_t1.p, c->fdm_t2.p); return; }
+  if (!c->comm.multi()) {
+    if (c->fdm_p_fused.built && k[0] == k[1] && k[1] == k[2]) fdmo_scalar_apply(s, c->fdm_p_fused, a, k[0], g, z);
+    else fdm_apply(s, c->fdm_p, a, k, g, z, c->fdm_t1.p, c->fdm_t2.p);
+    return;
+  }
   FdmDist &F = c->fdm_dist; const FdmScalar &L = c->fdm_p;
   const int dim = c->dim, N = F.n_ranks, r = F.rank, last = dim - 1;
   const int n0 = L.dir[0].n, nl = c->box.n[last] + 1;             // local planes incl. the shared ones

@@ -207,6 +207,7 @@ struct OctPass {
   int hx, pl;               // mode 1: columns of a plane = hx hy; a column's plane offset -> (my, mx)
   const double *T1[3][2], *T2[3][2];                     // [component][parity], MFMA fragment order [tile][4 NT][64]
   const double *lam_z[3][2]; double cz[3]; const double *bxy;   // mode 1: eigenvalues of the line direction; bxy[(4 c + (o & 3)) pl + column] = the other two directions' share
+  int vec2;                     // rows are 16-byte aligned (even pitch, even chunk offsets): 16-byte block loads; 0: 8-byte loads (the scalar Q1 systems keep their nodal layout)
   const PcgScalars *gate;       // inside a PCG iteration: the launch is a no-op once the solve has finished (the host enqueues iterations ahead of the device-side stopping test)
   unsigned long long *stamps;   // diagnostic (PORO_FDMO_STAMPS): per block 8 words: 100 MHz time at start / block in LDS / GEMM 1 done / intermediate in LDS / GEMM 2 done / stored, HW_ID, XCC_ID
 };
@@ -259,7 +260,8 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP);
-      stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
+      if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
+      else { const double *src = in + base + (int64_t)r * P.row_stride + c2; stage[u].x = (e < TOT && r < R && c2 < C) ? src[0] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? src[1] : 0.0; }
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) { const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP); if (e < TOT) *reinterpret_cast<double2 *>(&L[r * LD1 + c2]) = stage[u]; }
@@ -461,7 +463,7 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
   P.co_stride = O.co_stride; P.hx = hxp; P.pl = hxp * hy;
-  P.bxy = O.bxy.p; P.gate = gate;
+  P.bxy = O.bxy.p; P.gate = gate; P.vec2 = 1;
   for (int c = 0; c < 3; ++c) { P.cz[c] = O.coef[c][2]; for (int p = 0; p < 2; ++p) P.lam_z[c][p] = O.lam[c][2][p].p; }
   // pass 1: per z-plane, X[ky][kx] -> Fy (X Fx^T)
   P.mode = 0; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 0; P.bit2 = 1;
@@ -491,6 +493,54 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
       std::fclose(f);
     }
   }
+}
+
+// ---- the same three sweeps for a SCALAR Q1 system of the box (pressure Jacobian a M + kappa K, projection mass matrix): one "component", no parity octants, the
+// vectors keep their nodal layout [z][y][x] (full-length lines, odd pitch: 8-byte block loads).  Replaces six single-direction launches of kernels_fdm.hip.
+bool fdmo_scalar_usable(int dim, const int nn[3]) { if (dim != 3) return false; for (int d = 0; d < 3; ++d) if (nn[d] > 80 || nn[d] < 2) return false; return true; }
+void fdmo_scalar_init(FdmOct &O, const int nn[3], hipStream_t s) {
+  int hmax = 1;
+  for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = nn[d]; hmax = std::max(hmax, nn[d]); }
+  O.nt = (hmax + 15) / 16; O.hxp = nn[0];
+  O.co_stride = (int64_t)nn[0] * nn[1] * nn[2]; O.n_oct = O.co_stride;
+  O.t.alloc(O.n_oct); O.t.zero(s);
+}
+void fdmo_scalar_upload_dir(FdmOct &O, int dir, const std::vector<double> &S, const std::vector<double> &lam, int n) {   // S: n x n row-major, columns = M-orthonormal eigenvectors
+  const int nt = O.nt, kkp = 4 * nt, padn = 16 * nt;
+  std::vector<double> F((size_t)nt * kkp * 64, 0.0), B((size_t)nt * kkp * 64, 0.0), lp(padn + 16, std::numeric_limits<double>::infinity());
+  for (int t = 0; t < nt; ++t) for (int kk = 0; kk < kkp; ++kk) for (int l = 0; l < 64; ++l) {
+    const int r = 16 * t + (l & 15), cc = 4 * kk + (l >> 4);
+    if (r < n && cc < n) { F[((size_t)t * kkp + kk) * 64 + l] = S[(size_t)cc * n + r]; B[((size_t)t * kkp + kk) * 64 + l] = S[(size_t)r * n + cc]; }
+  }
+  for (int m = 0; m < n; ++m) lp[m] = lam[m];
+  O.h_lam[0][dir][0] = lp; O.fwd[0][dir][0].upload(F); O.bwd[0][dir][0].upload(B); O.lam[0][dir][0].upload(lp);
+}
+// z = (a M + kappa K)^-1 g; the x / y share a + kappa (lam_x + lam_y) of the eigenvalue sums is tabulated per plane position, one table per (a, kappa)
+void fdmo_scalar_apply(hipStream_t s, FdmOct &O, double a, double kappa, const double *g, double *z, const PcgScalars *gate) {
+  const int nt = O.nt, hx = O.h[0], hy = O.h[1], hz = O.h[2];
+  const double *table = nullptr;
+  for (auto &T : O.scalar_tables) if (T.a == a && T.kappa == kappa) table = T.t.p;
+  if (!table) {
+    if (O.scalar_tables.size() >= 8) { PORO_HIP(hipStreamSynchronize(s)); O.scalar_tables.pop_front(); }   // (a changing coefficient, e.g. a varying time step: drop the oldest)
+    std::vector<double> Bt((size_t)hx * hy);
+    for (int my = 0; my < hy; ++my) for (int mx = 0; mx < hx; ++mx) Bt[(size_t)my * hx + mx] = a + kappa * (O.h_lam[0][0][0][mx] + O.h_lam[0][1][0][my]);
+    O.scalar_tables.emplace_back(); auto &T = O.scalar_tables.back(); T.a = a; T.kappa = kappa; T.t.upload(Bt); table = T.t.p;
+  }
+  auto tiles = [](int n) { return (n + 15) / 16; };
+  auto ksteps = [](int n) { return (n + 3) / 4; };
+  OctPass P{};
+  P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = table; P.gate = gate; P.vec2 = 0;
+  P.cz[0] = kappa; P.lam_z[0][0] = O.lam[0][2][0].p;
+  P.mode = 0; P.R = hy; P.C = hx; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hx * hy; P.row_stride = hx; P.bit1 = 0; P.bit2 = 1;
+  P.T1[0][0] = O.fwd[0][0][0].p; P.T2[0][0] = O.fwd[0][1][0].p;
+  launch_pass_nt(s, nt, P, P.nblk, g, O.t.p);
+  const int cw = 16 * std::min(nt, 4);
+  P.mode = 1; P.R = hz; P.C = cw; P.nt_r = tiles(hz); P.nt_c = cw / 16; P.kk1 = ksteps(hz); P.kk2 = ksteps(hz); P.nblk = (hx * hy + cw - 1) / cw; P.blk_stride = cw; P.row_stride = (int64_t)hx * hy; P.bit1 = 2; P.bit2 = 2;
+  P.T1[0][0] = O.fwd[0][2][0].p; P.T2[0][0] = O.bwd[0][2][0].p;
+  launch_pass_nt(s, nt, P, P.nblk, O.t.p, O.t.p);
+  P.mode = 2; P.R = hy; P.C = hx; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hy); P.kk2 = ksteps(hx); P.nblk = hz; P.blk_stride = (int64_t)hx * hy; P.row_stride = hx; P.bit1 = 1; P.bit2 = 0;
+  P.T1[0][0] = O.bwd[0][1][0].p; P.T2[0][0] = O.bwd[0][0][0].p;
+  launch_pass_nt(s, nt, P, P.nblk, O.t.p, z);
 }
 
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v, double *q) { hipLaunchKernelGGL(k_fdmo_from_nodal, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), v, (const uint8_t *)nullptr, q); }

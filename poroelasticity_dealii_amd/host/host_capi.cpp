@@ -200,6 +200,12 @@ int poro_host_runner_step(void *r, double *trace, int max_rows, int64_t *work) {
     return rows;
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+// roll back to the snapshot, then one time step, in ONE call (a benchmark that repeats a step pays one host-language round trip instead of two)
+int poro_host_runner_restore_and_step(void *r, double *trace, int max_rows, int64_t *work) {
+  try { auto *R = static_cast<HostRunner *>(r); if (R->dim == 2) R->p2->restore_state(); else R->p3->restore_state(); }
+  catch (const std::exception &e) { g_err = e.what(); return -1; }
+  return poro_host_runner_step(r, trace, max_rows, work);
+}
 // action 0: snapshot the device state, 1: roll back to it
 int poro_host_runner_state(void *r, int action) {
   try {
