@@ -104,6 +104,22 @@ struct FdmOct {
   DevBuf<double> g, z, t;                         // residual, preconditioned residual, scratch - all in octant form
   std::vector<double> h_lam[3][3][2];             // host copies of the eigenvalues
   DevBuf<double> bxy;                             // [component][py][px][my][mx] = coef_x lam_x[mx] + coef_y lam_y[my]: the part of the eigenvalue sum a z line shares (pass 2 reads it per column)
+  // slab-partitioned form ("quadrant form"): only x and y are split into parities in the CG vectors, Q[c][q = 2 py + px][kz local][ky][kx] (no = 4 blocks per component);
+  // the z transform runs on whole global lines after an all-to-all of column chunks, where the z butterfly is applied on the way in / out of the transposed array
+  int no = 8;                                     // blocks per component in g, z, t: 8 octants, or 4 quadrants when z is not split locally
+  int own_z = 0;                                  // local node planes that count in dot products (the upper shared plane belongs to the neighbour)
+  struct Slab {
+    bool on = false; int n_ranks = 1, rank = 0;
+    int ng = 0, hzg = 0;                          // global nodes / half length of a z line
+    int cw = 64, nchunk = 0, cps = 0, chunk0 = 0, my_chunks = 0;   // chunk width (columns), chunks per (component, quadrant) plane, chunks per rank share, this rank's first global chunk and count
+    int64_t scols = 0;                            // columns of a share = cps cw
+    int own = 0, nl = 0, max_own = 0, max_nl = 0, rows_back = 0;    // planes this rank sends (owns) / holds; maxima over the ranks; sum of the ranks' local planes
+    int64_t recv_off = 0;                         // buf = [send | recv], each [rank][plane][scols]; a rank's own block is written straight into the receive half
+    DevBuf<int64_t> row_in;                       // [ng]: offset (in buf) of global plane kz after the gathering all-to-all
+    DevBuf<int64_t> row_out; DevBuf<int32_t> row_kz;   // [rows_back]: offset (in buf) of a row of the scattering all-to-all, global plane of that row
+    DevBuf<int64_t> otab, itab;                   // [12 plane positions]: where pass 1 stores / pass 3 finds a column of plane 0 in buf (+ plane * scols)
+    DevBuf<double> buf, tz;                       // all-to-all buffers; transposed array [chunk][pz][hzg][cw]
+  } slab;
   struct ScalarTable { double a, kappa; DevBuf<double> t; };
   std::list<ScalarTable> scalar_tables;           // scalar form: a + kappa (lam_x + lam_y) per plane position, one table per (a, kappa) seen (pressure Jacobian, mass matrix)
 };
@@ -330,7 +346,8 @@ void fdmu_lines(hipStream_t s, const FdmU &F, const FdmuDir *last_dir, int64_t C
 // ---- kernels_fdmo.hip: octant form (see FdmOct) --------------------------------------------------
 bool fdmo_usable(int dim, const int nn[3]);          // 3D, half lines of at most 80 entries
 void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s);   // sizes + buffers
-// half-size transforms of (component, direction) from the generalised eigenvectors S (nn x nn row-major, every mode symmetric or antisymmetric) and eigenvalues lam
+// slab-partitioned form: nn = LOCAL nodes; layers[q] = node planes rank q holds minus one (its cell layers x degree); the last direction's matrices are uploaded for the GLOBAL line
+void fdmo_init_slab(FdmOct &O, const int nn[3], const double coef[3][3], int rank, const std::vector<int> &node_layers, bool has_upper, hipStream_t s);
 bool fdmo_upload_dir(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn);
 void fdmo_finalize(FdmOct &O);   // after every (component, direction) has been uploaded: derived tables
 void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_oct, double *scratch_oct, const PcgScalars *gate = nullptr, hipEvent_t *ev /* optional: 3 start / stop pairs attached to the three pass dispatches */ = nullptr);   // z = blockdiag(A_cc)^-1 g, all in octant form; gate: no-op once gate->done / finishing
@@ -344,8 +361,14 @@ void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r_oct, double *
 // the vector kernels of pcg() with g / z in octant form (same device-side scalar protocol as their nodal counterparts in kernels_la.hip)
 void fdmo_init_residual(hipStream_t s, const FdmOct &O, double *g_oct, const double *Ax, const double *b, const uint8_t *inert);
 void fdmo_first_direction(hipStream_t s, const FdmOct &O, double *d, const double *g_oct, const double *z_oct, double *partials /*2 sets: gg, gz*/);
-void fdmo_update_g(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, double *g_oct, const double *h, const uint8_t *inert, const double *partials_dh, double *partials_out /*gg*/);
-void fdmo_update_d(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, int it, double *x, double *d, const double *z_oct, const double *partials_in /*2 sets*/);
+// red != null (partitioned runs): the all-reduced d.h (update_g: red[0]) / g.g and g.z (update_d: red[0], red[1]) instead of the block partials
+void fdmo_update_g(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, double *g_oct, const double *h, const uint8_t *inert, const double *partials_dh, double *partials_out /*gg*/, const double *red = nullptr);
+void fdmo_update_d(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, int it, double *x, double *d, const double *z_oct, const double *partials_in /*2 sets*/, const double *red = nullptr);
+void fdmo_dot_owned(hipStream_t s, const FdmOct &O, const double *a_oct, const double *b_oct, double *partials, const PcgScalars *gate);   // block partials of a.b over the planes this rank owns
+// slab form: the pieces of one application around the two all-to-alls (ctx_prec.hip drives them)
+void fdmo_slab_pass(hipStream_t s, const FdmOct &O, int pass /*1, 2, 3*/, const double *in, double *out, const PcgScalars *gate, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// pass 1: quadrant layout -> slab.buf (send half; own share -> receive half); pass 2: gathered planes in slab.buf -> slab.tz; pass 3: scattered planes in slab.buf -> quadrant layout
+void fdmo_slab_scatter_pack(hipStream_t s, const FdmOct &O, const PcgScalars *gate);                            // slab.tz -> slab.buf (inverse butterfly; every rank's planes incl. the shared ones)
 // dot_partials (optional, kMaxPartials slots, zeroed by the caller once): per-workgroup partial sums of x.y, fused into the apply
 int kron_apply(hipStream_t s, const MfArgs &a, const double *x, double *y, bool constrained, int n_cus, double *dot_partials = nullptr, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                const PcgScalars *pcg = nullptr /* launch becomes a no-op once pcg->done / finishing is set */,

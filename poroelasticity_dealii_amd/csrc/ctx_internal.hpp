@@ -74,7 +74,8 @@ double estimate_lmax_u(poro_ctx *c, const ApplyFn &apply, const DiagVec &dj);
 // ---- fast-diagonalisation preconditioners (ctx_prec.hip) ------------------------------------------------------------------------------
 bool fdm_p_supported(poro_ctx *c);
 void build_fdm_p(poro_ctx *c);
-void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk);
+void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk, bool self_in_place = false /* the caller has already put its own block into recv */);
+void fdm_precondition_u_slab(poro_ctx *c, const double *g_quadrant, double *z_quadrant, const PcgScalars *gate);
 void fdm_precondition_p(poro_ctx *c, double a, const double k[3], const double *g, double *z);
 void analyse_fdm_u(poro_ctx *c);
 void build_fdm_u(poro_ctx *c);

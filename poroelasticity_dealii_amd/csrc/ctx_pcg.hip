@@ -83,11 +83,11 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
         const std::function<bool(const double *, double *, double *)> *precond, int *its_hint, bool precond_gated,
         const FdmOct *oct /* single rank, explicit preconditioner: the residual and z = P^-1 g live in octant form (kernels_fdmo.hip), `g` is unused */) {
   static const bool two_reductions = std::getenv("PORO_TWO_REDUCTION_CG") != nullptr;    // A/B hook: the three-kernel recurrence on partitioned runs too
-  if (c->comm.multi() && !two_reductions) return pcg_single_reduction(c, apply, n, plane, x, b, diag, g, d, h, opts, info, precond, its_hint);
+  if (c->comm.multi() && !two_reductions && !oct) return pcg_single_reduction(c, apply, n, plane, x, b, diag, g, d, h, opts, info, precond, its_hint);
   hipStream_t s = c->stream;
   const int prec = opts->preconditioner == PORO_PREC_JACOBI ? 1 : 0;
   double *zbuf = const_cast<double *>(diag.z);
-  if (oct) { if (!precond || c->comm.multi()) throw Error("pcg: the octant form needs an explicit preconditioner on one rank"); g = oct->g.p; zbuf = oct->z.p; }
+  if (oct) { if (!precond || c->comm.multi() != oct->slab.on) throw Error("pcg: the octant form needs an explicit preconditioner (one rank: octants, slab partition: quadrants)"); g = oct->g.p; zbuf = oct->z.p; }
   if (precond && !zbuf) throw Error("pcg: explicit preconditioner without a z vector");
   const int64_t n_own = owned(c, n, plane);
   const bool multi = c->comm.multi();
@@ -126,11 +126,14 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
       if (!apply(d, h, part_dh)) pcg_dot_dh(s, sc, d, h, n_own, part_dh);
       ++applies;
       if (multi) { pcg_scalars_sum(s, part_dh, 1, red); allreduce_sum(c, red, 1); }
-      if (oct) fdmo_update_g(s, *oct, sc, (it - 1) & 1, g, h, diag.inert, part_dh, part);
+      if (oct) fdmo_update_g(s, *oct, sc, (it - 1) & 1, g, h, diag.inert, part_dh, part, multi ? red : nullptr);
       else pcg_update_g_fused(s, sc, (it - 1) & 1, g, h, diag, prec, n, n_own, part_dh, multi ? red : nullptr, part);
-      if (precond && !(*precond)(g, zbuf, part + kMaxPartials)) la_dot_partials(s, g, zbuf, oct ? oct->n_oct : n_own, part + kMaxPartials, precond_gated ? sc : nullptr);
+      if (precond && !(*precond)(g, zbuf, part + kMaxPartials)) {
+        if (oct && multi) fdmo_dot_owned(s, *oct, g, zbuf, part + kMaxPartials, precond_gated ? sc : nullptr);
+        else la_dot_partials(s, g, zbuf, oct ? oct->n_oct : n_own, part + kMaxPartials, precond_gated ? sc : nullptr);
+      }
       if (multi) { pcg_scalars_sum(s, part, 2, red + 1); allreduce_sum(c, red + 1, 2); }
-      if (oct) fdmo_update_d(s, *oct, sc, (it - 1) & 1, it, x, d, zbuf, part);
+      if (oct) fdmo_update_d(s, *oct, sc, (it - 1) & 1, it, x, d, zbuf, part, multi ? red + 1 : nullptr);
       else pcg_update_d_fused(s, sc, (it - 1) & 1, it, x, d, g, diag, prec, n, part, multi ? red + 1 : nullptr);
     }
     post_and_wait(c, nullptr, 0, sc); hs = c->mailbox->sc;

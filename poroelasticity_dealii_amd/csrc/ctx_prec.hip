@@ -70,10 +70,10 @@ void build_fdm_p(poro_ctx *c) {
   c->fdm_p.built = true;
 }
 // every rank sends block q of `send` (blk doubles) to rank q and receives block q of `recv` from it
-void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk) {
+void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk, bool self_in_place) {
   Comm &cm = c->comm; const int N = cm.part.n_ranks, r = cm.part.rank;
   Timed tm(c, "alltoall");
-  PORO_HIP(hipMemcpyAsync(recv + (size_t)r * blk, send + (size_t)r * blk, blk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (!self_in_place) PORO_HIP(hipMemcpyAsync(recv + (size_t)r * blk, send + (size_t)r * blk, blk * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   if (N <= 1) return;
   if (cm.nccl_comm) {
     ncclComm_t comm = (ncclComm_t)cm.nccl_comm;
@@ -235,10 +235,13 @@ void build_fdm_u(poro_ctx *c) {
     F.sendbuf.zero(c->stream); F.recvbuf.zero(c->stream); F.tz1.zero(c->stream); F.tz2.zero(c->stream);
   }
   // octant form (kernels_fdmo.hip): one rank, 3D, every direction mirror-symmetric for every component, half lines of at most 80 entries
-  bool oct_ok = !multi && !F.single && !std::getenv("PORO_FDMU_NO_OCT");
-  { int nn3[3] = {F.nn[0], F.nn[1], F.nn[2]}; oct_ok = oct_ok && fdmo_usable(dim, nn3);
+  // slab partitions: the quadrant form (x, y split locally; the z butterfly next to the all-to-all) under the same conditions on the GLOBAL line
+  bool oct_ok = !F.single && !std::getenv("PORO_FDMU_NO_OCT");
+  { int nn3[3] = {F.nn[0], F.nn[1], F.nn[2]}, sym3[3] = {F.nn[0], F.nn[1], multi ? F.ng : F.nn[2]}; oct_ok = oct_ok && fdmo_usable(dim, sym3);
     for (int d = 0; d < dim && oct_ok; ++d) for (int comp = 0; comp < dim; ++comp) oct_ok = oct_ok && F.fix[comp][d][0] == F.fix[comp][d][1];
-    if (oct_ok) fdmo_init(c->fdm_oct, nn3, F.coef, c->stream); }
+    if (oct_ok && !multi) fdmo_init(c->fdm_oct, nn3, F.coef, c->stream);
+    if (oct_ok && multi) { std::vector<int> node_layers(F.n_ranks); for (int q = 0; q < F.n_ranks; ++q) node_layers[q] = ku * F.layers[q];
+                           fdmo_init_slab(c->fdm_oct, nn3, F.coef, F.rank, node_layers, c->comm.part.has_upper != 0, c->stream); } }
   // eigenpairs per (direction, end conditions); components with the same end conditions share the host work.  A direction takes the even / odd
   // form (half the MFMA work) when every component has the same condition at both ends there - all components of a pass share one kernel
   for (int d = 0; d < dim; ++d) {
@@ -267,7 +270,18 @@ void build_fdm_u(poro_ctx *c) {
   c->fdm_oct.built = oct_ok;
   F.built = true;
 }
-void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk);
+// slab form of the octant kernels: g, z in quadrant layout.  x / y sweeps on the local planes, whole z lines per column share between two all-to-alls
+void fdm_precondition_u_slab(poro_ctx *c, const double *g, double *z, const PcgScalars *gate) {
+  Timed tm(c, "precondition_u_fdm");
+  hipStream_t s = c->stream; FdmOct &O = c->fdm_oct; auto &S = O.slab;
+  double *send = S.buf.p, *recv = S.buf.p + S.recv_off;
+  fdmo_slab_pass(s, O, 1, g, S.buf.p, gate);                                          // x, y forward on the local planes; the owned planes go straight into the exchange buffer
+  alltoall_blocks(c, send, recv, (int64_t)S.max_own * S.scols, true);
+  fdmo_slab_pass(s, O, 2, S.buf.p, S.tz.p, gate);                                     // whole z lines of this rank's column share (parity parts formed on load): forward, scale, backward
+  { Timed tp(c, "fdm_u_slab_scatter_pack"); fdmo_slab_scatter_pack(s, O, gate); }                                                 // v_k = a + b, v_k' = a - b, every rank's planes (shared ones to both)
+  alltoall_blocks(c, send, recv, (int64_t)S.max_nl * S.scols, true);
+  fdmo_slab_pass(s, O, 3, S.buf.p, z, gate);                                          // y, x backward, reading the received planes in place
+}
 void fdm_precondition_u(poro_ctx *c, const double *g, double *z) {
   Timed tm(c, "precondition_u_fdm");
   hipStream_t s = c->stream; FdmU &F = c->fdm_u;

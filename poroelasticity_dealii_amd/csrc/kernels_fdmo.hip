@@ -33,7 +33,8 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-struct OctDims { int nx, ny, nz, hx, hy, hz, hxp; int64_t co; };   // nodes and half lengths per direction; hxp = row pitch (hx rounded up to even: 16-byte aligned rows, the pad entry stays zero); co = hxp hy hz entries per (component, octant)
+struct OctDims { int nx, ny, nz, hx, hy, hz, hxp; int64_t co; int no, own_z; };   // nodes and half lengths per direction; hxp = row pitch (hx rounded up to even: 16-byte aligned rows, the pad entry stays zero); co = hxp hy hz entries per (component, octant)
+// no = 8: octant form.  no = 4 (slab partitions): z is not split - every z index is "its own mirror image" (hz = nz, parity blocks 0..3 only); own_z = planes that count in dot products
 
 // ---- the 8-point butterfly --------------------------------------------------------------------------------------------------------------
 // index bit 0 / 1 / 2 = x / y / z.  Forward: in = values at the lower node (bit clear) and its mirror image (bit set), out = even (bit clear) and odd
@@ -62,13 +63,13 @@ __device__ __forceinline__ void bfly_bwd(double (&v)[8], const bool (&centre)[3]
   }
 }
 struct OctPos {
-  int64_t node[8]; bool centre[3]; bool live[8]; double weight; bool valid;
+  int64_t node[8]; bool centre[3]; bool live[8]; double weight; bool valid, own;
   // lower-octant position idx = (kz hy + ky) hxp + kx -> the eight mirror nodes; live[m]: node m is distinct from the ones with fewer mirrored directions; valid: not a row pad
   __device__ __forceinline__ OctPos(const OctDims &D, int64_t idx) {
     const int kx = (int)(idx % D.hxp), ky = (int)((idx / D.hxp) % D.hy), kz = (int)(idx / ((int64_t)D.hxp * D.hy));
     valid = kx < D.hx;
-    const int mx = D.nx - 1 - kx, my = D.ny - 1 - ky, mz = D.nz - 1 - kz;
-    centre[0] = mx == kx; centre[1] = my == ky; centre[2] = mz == kz;
+    const int mx = D.nx - 1 - kx, my = D.ny - 1 - ky, mz = D.no == 8 ? D.nz - 1 - kz : kz;
+    centre[0] = mx == kx; centre[1] = my == ky; centre[2] = mz == kz; own = kz < D.own_z;
     weight = (centre[0] ? 1.0 : 0.5) * (centre[1] ? 1.0 : 0.5) * (centre[2] ? 1.0 : 0.5);   // |v|^2 over a mirror orbit = weight * sum of the squared parity parts
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_from_nodal(OctDims D, const dou
     for (int m = 0; m < 8; ++m) { const int64_t dof = P.node[m] * 3 + c; w[m] = (inert && inert[dof]) ? 0.0 : v[dof]; }
     bfly_fwd(w, P.centre);
 #pragma unroll
-    for (int o = 0; o < 8; ++o) q[(int64_t)(c * 8 + o) * D.co + idx] = w[o];
+    for (int o = 0; o < 8; ++o) if (o < D.no) q[(int64_t)(c * D.no + o) * D.co + idx] = w[o];
   }
 }
 __global__ void __launch_bounds__(kBlock) k_fdmo_to_nodal(OctDims D, const double *__restrict__ r, double *__restrict__ v) {
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_to_nodal(OctDims D, const doubl
     PORO_OCT_DECODE(D)
     double w[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) w[o] = r[(int64_t)(c * 8 + o) * D.co + idx];
+    for (int o = 0; o < 8; ++o) w[o] = o < D.no ? r[(int64_t)(c * D.no + o) * D.co + idx] : 0.0;
     bfly_bwd(w, P.centre);
 #pragma unroll
     for (int m = 0; m < 8; ++m) if (P.live[m]) v[P.node[m] * 3 + c] = w[m];
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_init_residual(OctDims D, double
     for (int m = 0; m < 8; ++m) { const int64_t dof = P.node[m] * 3 + c; w[m] = (inert && inert[dof]) ? 0.0 : Ax[dof] - b[dof]; }
     bfly_fwd(w, P.centre);
 #pragma unroll
-    for (int o = 0; o < 8; ++o) g[(int64_t)(c * 8 + o) * D.co + idx] = w[o];
+    for (int o = 0; o < 8; ++o) if (o < D.no) g[(int64_t)(c * D.no + o) * D.co + idx] = w[o];
   }
 }
 // d = -z (nodal); block partials of g.g and g.z
@@ -129,10 +130,10 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_first_direction(OctDims D, doub
   double gg = 0, gz = 0;
   PORO_OCT_LOOP(D) {
     PORO_OCT_DECODE(D)
-    double w[8]; double s2 = 0;
+    double w[8]; double s2 = 0, sz = 0;
 #pragma unroll
-    for (int o = 0; o < 8; ++o) { const int64_t at = (int64_t)(c * 8 + o) * D.co + idx; const double gv = g[at]; w[o] = z[at]; s2 = fma(gv, gv, s2); gz = fma(gv, w[o], gz); }
-    gg = fma(P.weight, s2, gg);
+    for (int o = 0; o < 8; ++o) { w[o] = 0.0; if (o < D.no) { const int64_t at = (int64_t)(c * D.no + o) * D.co + idx; const double gv = g[at]; w[o] = z[at]; s2 = fma(gv, gv, s2); sz = fma(gv, w[o], sz); } }
+    if (P.own) { gg = fma(P.weight, s2, gg); gz += sz; }
     bfly_bwd(w, P.centre);
 #pragma unroll
     for (int m = 0; m < 8; ++m) if (P.live[m]) d[P.node[m] * 3 + c] = -w[m];
@@ -141,11 +142,11 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_first_direction(OctDims D, doub
   store_partial(partials, gg); store_partial(partials + kMaxPartials, gz);
 }
 // g += alpha H (A d) and the partials of g.g (g.z follows in a plain dot of the two octant arrays once z = P^-1 g exists)
-__global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctDims D, PcgScalars *sc, int parity, double *__restrict__ g, const double *__restrict__ h, const uint8_t *__restrict__ inert, const double *partials_dh, double *partials_out) {
+__global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctDims D, PcgScalars *sc, int parity, double *__restrict__ g, const double *__restrict__ h, const uint8_t *__restrict__ inert, const double *partials_dh, double *partials_out, const double *red) {
   __shared__ double sh[5];
   if (sc->done) return;
   if (sc->finishing) { if (blockIdx.x == 0 && threadIdx.x == 0) sc->done = 1; return; }   // (see k_pcg_update_g_fused)
-  const double dh = sum_partials(partials_dh, sh);
+  const double dh = red ? red[0] : sum_partials(partials_dh, sh);
   const double alpha = sc->gh2[parity] / dh;
   double gg = 0;
   PORO_OCT_LOOP(D) {
@@ -158,18 +159,18 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctDims D, PcgScalars 
     for (int m = 0; m < 8; ++m) w[m] = h[P.node[m] * 3 + c];
     bfly_fwd(w, P.centre);
 #pragma unroll
-    for (int o = 0; o < 8; ++o) { const int64_t at = (int64_t)(c * 8 + o) * D.co + idx; const double gv = fma(alpha, w[o], g[at]); g[at] = gv; s2 = fma(gv, gv, s2); }
-    gg = fma(P.weight, s2, gg);
+    for (int o = 0; o < 8; ++o) if (o < D.no) { const int64_t at = (int64_t)(c * D.no + o) * D.co + idx; const double gv = fma(alpha, w[o], g[at]); g[at] = gv; s2 = fma(gv, gv, s2); }
+    if (P.own) gg = fma(P.weight, s2, gg);
   }
   gg = block_sum(gg, sh);
   store_partial(partials_out, gg);
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
 }
 // x += alpha d, then d = beta d - H' z unless the solve just finished (k_pcg_update_d_fused with the explicit z in octant form)
-__global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars *sc, int parity, int it, double *__restrict__ x, double *__restrict__ d, const double *__restrict__ z, int64_t n_u, const double *partials_in) {
+__global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars *sc, int parity, int it, double *__restrict__ x, double *__restrict__ d, const double *__restrict__ z, int64_t n_u, const double *partials_in, const double *red) {
   __shared__ double sh[5];
   if (sc->done) return;
-  const double gg = sum_partials(partials_in, sh), gz = sum_partials(partials_in + kMaxPartials, sh);
+  const double gg = red ? red[0] : sum_partials(partials_in, sh), gz = red ? red[1] : sum_partials(partials_in + kMaxPartials, sh);
   const double res = sqrt(gg), gh_old = sc->gh2[parity], alpha = sc->alpha;
   const bool conv = res <= sc->tol, fail = !conv && it >= sc->max_iter;
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gg = gg; sc->gz = gz; sc->res = res; sc->it = it; }
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars 
     PORO_OCT_DECODE(D)
     double w[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) w[o] = z[(int64_t)(c * 8 + o) * D.co + idx];
+    for (int o = 0; o < 8; ++o) w[o] = o < D.no ? z[(int64_t)(c * D.no + o) * D.co + idx] : 0.0;
     bfly_bwd(w, P.centre);
 #pragma unroll
     for (int m = 0; m < 8; ++m) if (P.live[m]) {
@@ -193,6 +194,34 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars 
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->beta = beta; sc->gh2[parity ^ 1] = gz; }
+}
+
+// block partials of a . b over the planes this rank owns (slab form: the upper shared plane is the neighbour's)
+__global__ void __launch_bounds__(kBlock) k_fdmo_dot_owned(OctDims D, const double *__restrict__ a, const double *__restrict__ b, double *partials, const PcgScalars *gate) {
+  __shared__ double sh[5];
+  if (gate && (gate->done | gate->finishing)) return;
+  // every block of a, b is [plane][position]: the owned planes are its leading part (row pads are zeros in both)
+  const int64_t per = (int64_t)D.own_z * D.hxp * D.hy, total = 3 * D.no * per;
+  double acc = 0;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) { const int64_t blk = e / per, at = blk * D.co + (e - blk * per); acc = fma(a[at], b[at], acc); }
+  acc = block_sum(acc, sh);
+  store_partial(partials, acc);
+}
+
+// ---- slab form: the z transform needs whole global lines.  Columns = (component, quadrant, plane position), grouped in chunks of cw; rank q transforms chunks
+//      [q cps, (q + 1) cps).  Two all-to-alls of [rank][plane][share column] buffers; the z butterfly rides in the unpack / pack next to the transposed array ----
+struct SlabGeo { int cw, nchunk, cps, chunk_total, rank, my_chunks, hzg, ng; int64_t scols, pl, co; };
+// transposed array -> send buffer: every rank's planes (shared ones to both owners), v_k = a + b, v_k' = a - b
+__global__ void __launch_bounds__(256) k_fdmo_slab_scatter_pack(SlabGeo S, int rows, const int64_t *__restrict__ row_out, const int32_t *__restrict__ row_kz,
+                                                                  const double *__restrict__ tz, double *__restrict__ buf, const PcgScalars *gate) {
+  if (gate && (gate->done | gate->finishing)) return;
+  const int per_row = S.my_chunks * S.cw, total = rows * per_row;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int row = e / per_row, col = e - row * per_row, cl = col / S.cw, j = col - cl * S.cw;
+    const int kz = row_kz[row], mz = S.ng - 1 - kz, kh = min(kz, mz);
+    const double a = tz[((int64_t)(2 * cl) * S.hzg + kh) * S.cw + j], b = tz[((int64_t)(2 * cl + 1) * S.hzg + kh) * S.cw + j];
+    buf[row_out[row] + col] = kz == mz ? a : (kz < mz ? a + b : a - b);
+  }
 }
 
 // ---- the transform pass --------------------------------------------------------------------------------------------------------------------
@@ -207,6 +236,12 @@ struct OctPass {
   int hx, pl;               // mode 1: columns of a plane = hx hy; a column's plane offset -> (my, mx)
   const double *T1[3][2], *T2[3][2];                     // [component][parity], MFMA fragment order [tile][4 NT][64]
   const double *lam_z[3][2]; double cz[3]; const double *bxy;   // mode 1: eigenvalues of the line direction; bxy[(4 c + (o & 3)) pl + column] = the other two directions' share
+  int no_shift;                 // log2 of the blocks per component (3: octants, 2: quadrants of the slab form, 0: scalar system)
+  int slab_z, chunk0, chunk_total, nchunk;   // slab form, pass 2: workgroup = (local chunk, z parity) of the transposed array; its global chunk number gives (component, quadrant, chunk of the plane)
+  // slab form: the copies around the all-to-alls ride in the passes.  otab (pass 1): entry [block plane position] = where that column lives in the [send | recv] buffer for plane 0
+  // (+ plane * tab_plane; planes >= store_planes belong to the neighbour and are not sent); itab (pass 3): the same for the received planes; row_in (pass 2): offset of every
+  // global plane in the gathered buffer - the block is loaded as even / odd combination of a plane and its mirror image
+  const int64_t *otab, *itab, *row_in; int64_t tab_plane; int store_planes, ng;
   int vec2;                     // rows are 16-byte aligned (even pitch, even chunk offsets): 16-byte block loads; 0: 8-byte loads (the scalar Q1 systems keep their nodal layout)
   const PcgScalars *gate;       // inside a PCG iteration: the launch is a no-op once the solve has finished (the host enqueues iterations ahead of the device-side stopping test)
   unsigned long long *stamps;   // diagnostic (PORO_FDMO_STAMPS): per block 8 words: 100 MHz time at start / block in LDS / GEMM 1 done / intermediate in LDS / GEMM 2 done / stored, HW_ID, XCC_ID
@@ -245,9 +280,16 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   if (P.gate && (P.gate->done | P.gate->finishing)) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.x % P.nblk, co = blockIdx.x / P.nblk, c = co >> 3, o = co & 7;
+  int b, c, o, co = 0; int64_t base;
+  if (MODE == 1 && P.slab_z) {
+    const int G = P.chunk0 + (int)(blockIdx.x >> 1), cq = G / P.nchunk;
+    if (G >= P.chunk_total) return;                                  // (the last rank's share may be short; workgroup-uniform, before any barrier)
+    b = G - cq * P.nchunk; c = cq >> 2; o = (cq & 3) | ((blockIdx.x & 1) << 2); base = (int64_t)blockIdx.x * P.blk_stride;
+  } else {
+    co = blockIdx.x / P.nblk;
+    b = blockIdx.x % P.nblk; c = co >> P.no_shift; o = co & ((1 << P.no_shift) - 1); base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
+  }
   const bool heavy = CORNER && w == (int)(blockIdx.x & (NW - 1));   // this wave also computes tile (XT, XT)
-  const int64_t base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
   const int R = P.R, C = MODE == 1 ? min(P.C, P.pl - b * P.C) : P.C;
   const double *__restrict__ T1 = P.T1[c][(o >> P.bit1) & 1] + lane, *__restrict__ T2 = P.T2[c][(o >> P.bit2) & 1] + lane;
   auto stamp = [&](int k) { if (P.stamps && tid == 0) P.stamps[(int64_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime(); };
@@ -260,7 +302,13 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP);
-      if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
+      if (MODE == 1 && P.row_in) {             // gathered planes -> parity part of the global line: e_k = v_k + v_k', o_k = v_k - v_k' (centre plane: e = v, o = 0)
+        const bool ok = e < TOT && r < R && c2 < C; const int rr = ok ? r : 0, mr = P.ng - 1 - rr; const int64_t cb = (int64_t)(blockIdx.x >> 1) * P.C + c2;
+        const double2 lo = ok ? *reinterpret_cast<const double2 *>(in + P.row_in[rr] + cb) : double2{0.0, 0.0}, hi = (ok && mr != rr) ? *reinterpret_cast<const double2 *>(in + P.row_in[mr] + cb) : double2{0.0, 0.0};
+        const bool odd = blockIdx.x & 1;
+        stage[u].x = odd ? (mr != rr ? lo.x - hi.x : 0.0) : lo.x + hi.x; stage[u].y = odd ? (mr != rr ? lo.y - hi.y : 0.0) : lo.y + hi.y;
+      } else if (MODE == 2 && P.itab) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + P.itab[(int64_t)co * P.pl + (int64_t)r * P.row_stride + c2] + (int64_t)b * P.tab_plane) : double2{0.0, 0.0};
+      else if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
       else { const double *src = in + base + (int64_t)r * P.row_stride + c2; stage[u].x = (e < TOT && r < R && c2 < C) ? src[0] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? src[1] : 0.0; }
     }
 #pragma unroll
@@ -371,7 +419,11 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
     int tr, tc; tile_of(a, tr, tc, kColsSecond);
     if (a == NL + 1 && !heavy) continue;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int r = 16 * tr + 4 * q + kq, cc = 16 * tc + j; if (r < R && cc < C) out[base + (int64_t)r * P.row_stride + cc] = acc[a][q]; }
+    for (int q = 0; q < 4; ++q) {
+      const int r = 16 * tr + 4 * q + kq, cc = 16 * tc + j;
+      if (MODE == 0 && P.otab) { if (r < R && cc < C && b < P.store_planes) out[P.otab[(int64_t)co * P.pl + (int64_t)r * P.row_stride + cc] + (int64_t)b * P.tab_plane] = acc[a][q]; }
+      else if (r < R && cc < C) out[base + (int64_t)r * P.row_stride + cc] = acc[a][q];
+    }
   }
   if (P.stamps) {
     __builtin_amdgcn_s_waitcnt(0); __syncthreads(); stamp(5);
@@ -397,7 +449,8 @@ void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const
   }
 }
 inline int oct_grid(int64_t co) { return (int)std::min<int64_t>((3 * co + kBlock - 1) / kBlock, kMaxPartials); }   // threads = positions x components, as many per thread as the partial slots demand
-OctDims dims_of(const FdmOct &O) { return OctDims{O.n[0], O.n[1], O.n[2], O.h[0], O.h[1], O.h[2], O.hxp, O.co_stride}; }
+OctDims dims_of(const FdmOct &O) { return OctDims{O.n[0], O.n[1], O.n[2], O.h[0], O.h[1], O.h[2], O.hxp, O.co_stride, O.no, O.own_z}; }
+SlabGeo geo_of(const FdmOct &O) { const auto &S = O.slab; return SlabGeo{S.cw, S.nchunk, S.cps, 3 * O.no * S.nchunk, S.rank, S.my_chunks, S.hzg, S.ng, S.scols, (int64_t)O.hxp * O.h[1], O.co_stride}; }
 
 }  // namespace
 
@@ -412,14 +465,50 @@ void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t 
   for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = (nn[d] + 1) / 2; hmax = std::max(hmax, O.h[d]); for (int c = 0; c < 3; ++c) O.coef[c][d] = coef[c][d]; }
   O.nt = (hmax + 15) / 16;
   O.hxp = (O.h[0] + 1) & ~1;
-  O.co_stride = (int64_t)O.hxp * O.h[1] * O.h[2]; O.n_oct = 24 * O.co_stride;
+  O.co_stride = (int64_t)O.hxp * O.h[1] * O.h[2]; O.n_oct = 24 * O.co_stride; O.no = 8; O.own_z = O.n[2];
   O.g.alloc(O.n_oct); O.z.alloc(O.n_oct); O.t.alloc(O.n_oct);
   O.g.zero(s); O.z.zero(s); O.t.zero(s);
+}
+void fdmo_init_slab(FdmOct &O, const int nn[3], const double coef[3][3], int rank, const std::vector<int> &node_layers, bool has_upper, hipStream_t s) {
+  auto &S = O.slab; const int N = (int)node_layers.size();
+  S.on = true; S.n_ranks = N; S.rank = rank;
+  S.ng = 1; for (int q = 0; q < N; ++q) S.ng += node_layers[q];
+  S.hzg = (S.ng + 1) / 2;
+  if (nn[2] != node_layers[rank] + 1) throw Error("fdmo_init_slab: local planes do not match the layer table");
+  int hmax = S.hzg;
+  for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = d < 2 ? (nn[d] + 1) / 2 : nn[d]; if (d < 2) hmax = std::max(hmax, O.h[d]); for (int c = 0; c < 3; ++c) O.coef[c][d] = coef[c][d]; }
+  O.nt = (hmax + 15) / 16;
+  O.hxp = (O.h[0] + 1) & ~1; O.no = 4; O.own_z = has_upper ? nn[2] - 1 : nn[2];
+  O.co_stride = (int64_t)O.hxp * O.h[1] * O.h[2]; O.n_oct = 12 * O.co_stride;
+  O.g.alloc(O.n_oct); O.z.alloc(O.n_oct); O.t.alloc(O.n_oct);
+  O.g.zero(s); O.z.zero(s); O.t.zero(s);
+  const int64_t pl = (int64_t)O.hxp * O.h[1];
+  S.cw = 16 * std::min(O.nt, 4); S.nchunk = (int)((pl + S.cw - 1) / S.cw);
+  const int chunk_total = 12 * S.nchunk;
+  S.cps = (chunk_total + N - 1) / N; S.chunk0 = rank * S.cps; S.my_chunks = std::max(0, std::min(S.cps, chunk_total - S.chunk0)); S.scols = (int64_t)S.cps * S.cw;
+  std::vector<int> off(N), own(N), nl(N); int acc = 0; S.max_own = S.max_nl = S.rows_back = 0;
+  for (int q = 0; q < N; ++q) { off[q] = acc; acc += node_layers[q]; own[q] = node_layers[q] + (q == N - 1 ? 1 : 0); nl[q] = node_layers[q] + 1; S.max_own = std::max(S.max_own, own[q]); S.max_nl = std::max(S.max_nl, nl[q]); S.rows_back += nl[q]; }
+  S.own = own[rank]; S.nl = nl[rank];
+  if ((int64_t)std::max(S.max_own, S.max_nl) * chunk_total * S.cw >= (int64_t)1 << 31 || (int64_t)S.rows_back * S.scols >= (int64_t)1 << 31) throw Error("fdmo_init_slab: a slab of more than 2^31 transform entries");
+  // one buffer [send | recv]; what a rank keeps for itself is written straight into the receive half
+  const int64_t blk = (int64_t)std::max(S.max_own, S.max_nl) * S.scols; S.recv_off = blk * N;
+  std::vector<int64_t> rin(S.ng), rout(S.rows_back); std::vector<int32_t> rkz(S.rows_back);
+  for (int q = 0; q < N; ++q) for (int k = 0; k < own[q]; ++k) rin[off[q] + k] = S.recv_off + ((int64_t)q * S.max_own + k) * S.scols;
+  { int r = 0; for (int q = 0; q < N; ++q) for (int k = 0; k < nl[q]; ++k, ++r) { rout[r] = ((int64_t)q * S.max_nl + k) * S.scols + (q == rank ? S.recv_off : 0); rkz[r] = off[q] + k; } }
+  std::vector<int64_t> otab((size_t)12 * pl), itab((size_t)12 * pl);
+  for (int cq = 0; cq < 12; ++cq) for (int64_t col = 0; col < pl; ++col) {
+    const int b = (int)(col / S.cw), j = (int)(col % S.cw), G = cq * S.nchunk + b, dest = G / S.cps, cl = G % S.cps;
+    otab[(size_t)cq * pl + col] = (dest == rank ? S.recv_off : 0) + (int64_t)dest * S.max_own * S.scols + (int64_t)cl * S.cw + j;
+    itab[(size_t)cq * pl + col] = S.recv_off + (int64_t)dest * S.max_nl * S.scols + (int64_t)cl * S.cw + j;
+  }
+  S.row_in.upload(rin); S.row_out.upload(rout); S.row_kz.upload(rkz); S.otab.upload(otab); S.itab.upload(itab);
+  S.buf.alloc((size_t)2 * blk * N); S.tz.alloc((size_t)2 * S.cps * S.hzg * S.cw);
+  S.buf.zero(s); S.tz.zero(s);
 }
 
 bool fdmo_upload_dir(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn) {
   const int h = (nn + 1) / 2, nt = O.nt, kkp = 4 * nt, padn = 16 * nt;
-  if (nn != O.n[dir]) throw Error("fdmo_upload_dir: line length mismatch");
+  if (nn != (O.slab.on && dir == 2 ? O.slab.ng : O.n[dir])) throw Error("fdmo_upload_dir: line length mismatch");
   std::vector<int> grp[2];
   for (int m = 0; m < nn; ++m) {
     if (!(lam[m] < 1e300)) continue;              // removed modes
@@ -463,7 +552,7 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
   P.co_stride = O.co_stride; P.hx = hxp; P.pl = hxp * hy;
-  P.bxy = O.bxy.p; P.gate = gate; P.vec2 = 1;
+  P.bxy = O.bxy.p; P.gate = gate; P.vec2 = 1; P.no_shift = 3;
   for (int c = 0; c < 3; ++c) { P.cz[c] = O.coef[c][2]; for (int p = 0; p < 2; ++p) P.lam_z[c][p] = O.lam[c][2][p].p; }
   // pass 1: per z-plane, X[ky][kx] -> Fy (X Fx^T)
   P.mode = 0; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 0; P.bit2 = 1;
@@ -493,6 +582,38 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
       std::fclose(f);
     }
   }
+}
+
+// ---- slab form: the three sweeps as separate entry points (two all-to-alls sit between them, ctx_prec.hip) ----
+void fdmo_slab_pass(hipStream_t s, const FdmOct &O, int pass, const double *in, double *out, const PcgScalars *gate, hipEvent_t e0, hipEvent_t e1) {
+  const auto &S = O.slab; const int nt = O.nt, hx = O.h[0], hy = O.h[1], nzl = O.h[2], hxp = O.hxp;
+  auto tiles = [](int n) { return (n + 15) / 16; };
+  auto ksteps = [](int n) { return (n + 3) / 4; };
+  OctPass P{};
+  P.co_stride = O.co_stride; P.hx = hxp; P.pl = hxp * hy; P.bxy = O.bxy.p; P.gate = gate; P.vec2 = 1; P.no_shift = 2;
+  for (int c = 0; c < 3; ++c) { P.cz[c] = O.coef[c][2]; for (int p = 0; p < 2; ++p) P.lam_z[c][p] = O.lam[c][2][p].p; }
+  if (pass == 2) {
+    P.mode = 1; P.R = S.hzg; P.C = S.cw; P.nt_r = tiles(S.hzg); P.nt_c = S.cw / 16; P.kk1 = P.kk2 = ksteps(S.hzg); P.nblk = 1; P.blk_stride = (int64_t)S.hzg * S.cw; P.row_stride = S.cw; P.bit1 = P.bit2 = 2;
+    P.slab_z = 1; P.chunk0 = S.chunk0; P.chunk_total = 12 * S.nchunk; P.nchunk = S.nchunk; P.row_in = S.row_in.p; P.ng = S.ng;
+    for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][2][p].p; P.T2[c][p] = O.bwd[c][2][p].p; }
+    if (S.my_chunks > 0) launch_pass_nt(s, nt, P, 2 * S.my_chunks, in, out, e0, e1);
+    return;
+  }
+  const bool first = pass == 1;
+  P.mode = first ? 0 : 2; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(first ? hx : hy); P.kk2 = ksteps(first ? hy : hx); P.nblk = nzl; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp;
+  P.bit1 = first ? 0 : 1; P.bit2 = first ? 1 : 0;
+  for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = first ? O.fwd[c][0][p].p : O.bwd[c][1][p].p; P.T2[c][p] = first ? O.fwd[c][1][p].p : O.bwd[c][0][p].p; }
+  if (first) { P.otab = S.otab.p; P.store_planes = S.own; } else P.itab = S.itab.p;
+  P.tab_plane = S.scols;
+  launch_pass_nt(s, nt, P, 12 * P.nblk, in, out, e0, e1);
+}
+static int copy_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
+void fdmo_slab_scatter_pack(hipStream_t s, const FdmOct &O, const PcgScalars *gate) {
+  const auto &S = O.slab; const SlabGeo G = geo_of(O);
+  if (S.my_chunks > 0) hipLaunchKernelGGL(k_fdmo_slab_scatter_pack, copy_grid((int64_t)S.rows_back * S.my_chunks * S.cw), 256, 0, s, G, S.rows_back, S.row_out.p, S.row_kz.p, S.tz.p, S.buf.p, gate);
+}
+void fdmo_dot_owned(hipStream_t s, const FdmOct &O, const double *a, const double *b, double *partials, const PcgScalars *gate) {
+  hipLaunchKernelGGL(k_fdmo_dot_owned, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), a, b, partials, gate);
 }
 
 // ---- the same three sweeps for a SCALAR Q1 system of the box (pressure Jacobian a M + kappa K, projection mass matrix): one "component", no parity octants, the
@@ -529,7 +650,7 @@ void fdmo_scalar_apply(hipStream_t s, FdmOct &O, double a, double kappa, const d
   auto tiles = [](int n) { return (n + 15) / 16; };
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
-  P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = table; P.gate = gate; P.vec2 = 0;
+  P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = table; P.gate = gate; P.vec2 = 0; P.no_shift = 0;
   P.cz[0] = kappa; P.lam_z[0][0] = O.lam[0][2][0].p;
   P.mode = 0; P.R = hy; P.C = hx; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hx * hy; P.row_stride = hx; P.bit1 = 0; P.bit2 = 1;
   P.T1[0][0] = O.fwd[0][0][0].p; P.T2[0][0] = O.fwd[0][1][0].p;
@@ -551,11 +672,11 @@ void fdmo_init_residual(hipStream_t s, const FdmOct &O, double *g, const double 
 void fdmo_first_direction(hipStream_t s, const FdmOct &O, double *d, const double *g, const double *z, double *partials) {
   hipLaunchKernelGGL(k_fdmo_first_direction, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), d, g, z, partials);
 }
-void fdmo_update_g(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, double *g, const double *h, const uint8_t *inert, const double *partials_dh, double *partials_out) {
-  hipLaunchKernelGGL(k_fdmo_update_g, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), sc, parity, g, h, inert, partials_dh, partials_out);
+void fdmo_update_g(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, double *g, const double *h, const uint8_t *inert, const double *partials_dh, double *partials_out, const double *red) {
+  hipLaunchKernelGGL(k_fdmo_update_g, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), sc, parity, g, h, inert, partials_dh, partials_out, red);
 }
-void fdmo_update_d(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, int it, double *x, double *d, const double *z, const double *partials_in) {
-  hipLaunchKernelGGL(k_fdmo_update_d, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), sc, parity, it, x, d, z, (int64_t)3 * O.n[0] * O.n[1] * O.n[2], partials_in);
+void fdmo_update_d(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, int it, double *x, double *d, const double *z, const double *partials_in, const double *red) {
+  hipLaunchKernelGGL(k_fdmo_update_d, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), sc, parity, it, x, d, z, (int64_t)3 * O.n[0] * O.n[1] * O.n[2], partials_in, red);
 }
 
 }  // namespace poro

@@ -34,3 +34,4 @@ def test_config4_partition_8_slabs_of_9_layers():
     assert max(max(s) for s in rec["cg_iterations_u_by_rank"][0]) <= 20
     it = rec["per_cg_iteration_u_on_an_interior_rank"]
     assert it["operator_applications"] <= 1.3 and it["alltoalls_all_systems"] <= 5.0, it   # per iteration: 1 operator application (+ the initial residual), 2 all-to-alls (+ the share of the pressure / projection solves: 16 per step)
+    assert it["block_fdm_applications_in_slab_form"] >= 1.0, it                          # the quadrant-form kernels (kernels_fdmo.hip) did the preconditioning, not the nodal fallback
