@@ -71,6 +71,7 @@ struct FdmDir { int n = 0; DevBuf<double> S, St, lam; };
 struct FdmScalar { int dim = 0; FdmDir dir[3]; bool built = false; };
 struct FdmScale { const double *lam[3]; int n[3]; double a, k[3]; int64_t ncol, col0, col_total; };   // divide by a + k0 lam0[i] + k1 lam1[j] + k2 lam2[k] at grid node (i, j, k); ncol > 0: column-distributed layout
 // partitioned (slab) form: the transforms of the leading directions are local, the last direction runs on columns gathered by an all-to-all
+struct FdmWindow { int n_planes; int64_t ncols_valid, grid_col0, grid_plane0; };   // one peer's share of a window copy (fdm_window_batch)
 struct FdmDist {
   bool built = false; int n_ranks = 1, rank = 0;
   std::vector<int> layers, off;                 // cell layers and first global plane of every rank
@@ -79,6 +80,7 @@ struct FdmDist {
   int max_own = 0, max_nl = 0;                  // padded plane counts of the two exchanges
   FdmDir last;                                  // global eigenvectors of the last direction
   DevBuf<double> sendbuf, recvbuf, tz1, tz2; std::vector<double> hsend, hrecv;
+  DevBuf<FdmWindow> windows;                    // [4][n_ranks]: the per-peer windows of the four copies around the two all-to-alls (one launch each)
 };
 
 // block fast diagonalisation of the displacement system (kernels_fdmu.hip): per (component, direction) the transform matrices S^T (fwd) and
@@ -117,7 +119,6 @@ struct FdmOct {
     int64_t recv_off = 0;                         // buf = [send | recv], each [rank][plane][scols]; a rank's own block is written straight into the receive half
     DevBuf<int64_t> row_in;                       // [ng]: offset (in buf) of global plane kz after the gathering all-to-all
     DevBuf<int64_t> row_out; DevBuf<int32_t> row_kz;   // [rows_back]: offset (in buf) of a row of the scattering all-to-all, global plane of that row
-    DevBuf<int64_t> otab, itab;                   // [12 plane positions]: where pass 1 stores / pass 3 finds a column of plane 0 in buf (+ plane * scols)
     DevBuf<double> buf, tz;                       // all-to-all buffers; transposed array [chunk][pz][hzg][cw]
   } slab;
   struct ScalarTable { double a, kappa; DevBuf<double> t; };
@@ -330,6 +331,8 @@ void box_rhs_u(hipStream_t s, int dim, const BoxCoupling &B, double alpha, const
 void box_asm_u_matrix(hipStream_t s, int dim, int k_u, const BoxDev &box, const double *Ke, const CsrDev &A, const uint8_t *mask, double *val);
 void box_proj_rhs(hipStream_t s, int dim, const BoxCoupling &B, const double *u, int n_comp, const int32_t *tensor_components, double *const *rhs);
 void q1_eig(int n_cells, double h, std::vector<double> &S, std::vector<double> &lam);   // host: generalised eigenpairs of the 1D Q1 stiffness / mass matrices
+// all peers' windows in one launch: block q of the dense side is dense + q blk (to_block: peer `self` goes to dense_self instead - its own block of the receive buffer)
+void fdm_window_batch(hipStream_t s, double *grid, double *dense, double *dense_self, int self, bool to_block, const FdmWindow *win, int n_peers, int n_planes_pad, int64_t C, int64_t grid_stride, int64_t blk);
 void fdm_window(hipStream_t s, double *dst, const double *src, bool to_block, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid, int64_t grid_stride, int64_t grid_col0, int64_t grid_plane0);
 void fdm_transform(hipStream_t s, const double *T, int n_l, int64_t SI, int64_t n_outer, const double *in, double *out, const FdmScale *scale);
 void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], const double *g, double *z, double *t1, double *t2);

@@ -65,6 +65,19 @@ void build_fdm_p(poro_ctx *c) {
     upload_dir(F.last, acc, c->box.h[last]);
     const size_t blk = (size_t)std::max(F.max_own, F.max_nl) * F.C;
     F.sendbuf.alloc(blk * N); F.recvbuf.alloc(blk * N); F.tz1.alloc((size_t)F.ng * F.C); F.tz2.alloc((size_t)F.ng * F.C);
+    F.sendbuf.zero(c->stream); F.recvbuf.zero(c->stream); F.tz1.zero(c->stream); F.tz2.zero(c->stream);
+    // the four window copies of an application, one entry per peer: local grid -> send blocks (own planes), gathered blocks -> whole lines, whole lines -> send blocks
+    // (every rank's planes incl. the shared ones), scattered blocks -> local grid
+    std::vector<FdmWindow> W((size_t)4 * N);
+    auto ncols_of = [&](int q) { return std::max<int64_t>(0, std::min<int64_t>(F.C, F.ncol_total - (int64_t)q * F.C)); };
+    const int own_r = F.layers[r] + (r == N - 1 ? 1 : 0), nl_r = c->box.n[last] + 1;
+    for (int q = 0; q < N; ++q) {
+      W[q] = FdmWindow{own_r, ncols_of(q), (int64_t)q * F.C, 0};
+      W[N + q] = FdmWindow{F.layers[q] + (q == N - 1 ? 1 : 0), F.C, 0, F.off[q]};
+      W[2 * N + q] = FdmWindow{F.layers[q] + 1, F.C, 0, F.off[q]};
+      W[3 * N + q] = FdmWindow{nl_r, ncols_of(q), (int64_t)q * F.C, 0};
+    }
+    F.windows.upload(W);
     F.built = true;
   }
   c->fdm_p.built = true;
@@ -113,23 +126,20 @@ void fdm_precondition_p(poro_ctx *c, double a, const double k[3], const double *
   if (dim == 3) { fdm_transform(s, L.dir[0].St.p, n0, 1, (int64_t)L.dir[1].n * nl, g, t1, nullptr); fdm_transform(s, L.dir[1].St.p, L.dir[1].n, n0, nl, t1, t2, nullptr); cur = t2; }
   else { fdm_transform(s, L.dir[0].St.p, n0, 1, nl, g, t1, nullptr); cur = t1; }
   // gather whole lines of the last direction for this rank's column group
-  const int own_r = F.layers[r] + (r == N - 1 ? 1 : 0);
   const int64_t blk1 = (int64_t)F.max_own * F.C;
-  auto ncols_of = [&](int q) { return std::max<int64_t>(0, std::min<int64_t>(F.C, F.ncol_total - (int64_t)q * F.C)); };
-  for (int q = 0; q < N; ++q) fdm_window(s, F.sendbuf.p + (size_t)q * blk1, cur, true, own_r, F.max_own, F.C, ncols_of(q), SIp, (int64_t)q * F.C, 0);
-  alltoall_blocks(c, F.sendbuf.p, F.recvbuf.p, blk1);
-  PORO_HIP(hipMemsetAsync(F.tz1.p, 0, (size_t)F.ng * F.C * sizeof(double), s));
-  for (int q = 0; q < N; ++q) fdm_window(s, F.tz1.p, F.recvbuf.p + (size_t)q * blk1, false, F.layers[q] + (q == N - 1 ? 1 : 0), F.max_own, F.C, F.C, F.C, 0, F.off[q]);
+  fdm_window_batch(s, const_cast<double *>(cur), F.sendbuf.p, F.recvbuf.p, r, true, F.windows.p, N, F.max_own, F.C, SIp, blk1);
+  alltoall_blocks(c, F.sendbuf.p, F.recvbuf.p, blk1, true);
+  fdm_window_batch(s, F.tz1.p, F.recvbuf.p, nullptr, r, false, F.windows.p + N, N, F.max_own, F.C, F.C, blk1);       // (the owned planes of all ranks cover every global plane: tz1 is overwritten in full)
   FdmScale sc{}; sc.a = a; sc.ncol = F.C; sc.col0 = (int64_t)r * F.C; sc.col_total = F.ncol_total;
   for (int d = 0; d < 3; ++d) { sc.lam[d] = d < dim ? (d == last ? F.last.lam.p : L.dir[d].lam.p) : nullptr; sc.k[d] = d < dim ? k[d] : 0.0; sc.n[d] = d < dim ? (d == last ? F.ng : L.dir[d].n) : 1; }
   fdm_transform(s, F.last.St.p, F.ng, F.C, 1, F.tz1.p, F.tz2.p, &sc);
   fdm_transform(s, F.last.S.p, F.ng, F.C, 1, F.tz2.p, F.tz1.p, nullptr);
   // scatter back: every rank gets all of its planes (shared ones included) of every column group
   const int64_t blk2 = (int64_t)F.max_nl * F.C;
-  for (int q = 0; q < N; ++q) fdm_window(s, F.sendbuf.p + (size_t)q * blk2, F.tz1.p, true, F.layers[q] + 1, F.max_nl, F.C, F.C, F.C, 0, F.off[q]);
-  alltoall_blocks(c, F.sendbuf.p, F.recvbuf.p, blk2);
+  fdm_window_batch(s, F.tz1.p, F.sendbuf.p, F.recvbuf.p, r, true, F.windows.p + 2 * N, N, F.max_nl, F.C, F.C, blk2);
+  alltoall_blocks(c, F.sendbuf.p, F.recvbuf.p, blk2, true);
   double *back = dim == 3 ? t2 : t1;
-  for (int q = 0; q < N; ++q) fdm_window(s, back, F.recvbuf.p + (size_t)q * blk2, false, nl, F.max_nl, F.C, ncols_of(q), SIp, (int64_t)q * F.C, 0);
+  fdm_window_batch(s, back, F.recvbuf.p, nullptr, r, false, F.windows.p + 3 * N, N, F.max_nl, F.C, SIp, blk2);
   if (dim == 3) { fdm_transform(s, L.dir[1].S.p, L.dir[1].n, n0, nl, t2, t1, nullptr); fdm_transform(s, L.dir[0].S.p, n0, 1, (int64_t)L.dir[1].n * nl, t1, z, nullptr); }
   else fdm_transform(s, L.dir[0].S.p, n0, 1, nl, t1, z, nullptr);
 }

@@ -136,8 +136,24 @@ __global__ void k_fdm_window(double *dst, const double *src, int to_block, int n
   else if (valid) dst[g] = src[idx];
 }
 
+__global__ void __launch_bounds__(256) k_fdm_window_batch(double *grid, double *dense, double *dense_self, int self, int to_block, const FdmWindow *__restrict__ win, int n_planes_pad, int64_t C, int64_t grid_stride, int64_t blk) {
+  const int q = blockIdx.y; const FdmWindow W = win[q];
+  double *blkp = ((to_block && q == self) ? dense_self : dense) + (int64_t)q * blk;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < (int64_t)n_planes_pad * C; idx += (int64_t)gridDim.x * 256) {
+    const int64_t k = idx / C, cc = idx - k * C;
+    const bool valid = k < W.n_planes && cc < W.ncols_valid;
+    const int64_t g = (W.grid_plane0 + k) * grid_stride + W.grid_col0 + cc;
+    if (to_block) blkp[idx] = valid ? grid[g] : 0.0;
+    else if (valid) grid[g] = blkp[idx];
+  }
+}
+
 }  // namespace
 
+void fdm_window_batch(hipStream_t s, double *grid, double *dense, double *dense_self, int self, bool to_block, const FdmWindow *win, int n_peers, int n_planes_pad, int64_t C, int64_t grid_stride, int64_t blk) {
+  const int64_t n = (int64_t)n_planes_pad * C;
+  if (n && n_peers) hipLaunchKernelGGL(k_fdm_window_batch, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024), (unsigned)n_peers), 256, 0, s, grid, dense, dense_self, self, to_block ? 1 : 0, win, n_planes_pad, C, grid_stride, blk);
+}
 void fdm_window(hipStream_t s, double *dst, const double *src, bool to_block, int n_planes, int n_planes_pad, int64_t C, int64_t ncols_valid, int64_t grid_stride,
                 int64_t grid_col0, int64_t grid_plane0) {
   const int64_t n = (int64_t)n_planes_pad * C;

@@ -201,9 +201,13 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_dot_owned(OctDims D, const doub
   __shared__ double sh[5];
   if (gate && (gate->done | gate->finishing)) return;
   // every block of a, b is [plane][position]: the owned planes are its leading part (row pads are zeros in both)
-  const int64_t per = (int64_t)D.own_z * D.hxp * D.hy, total = 3 * D.no * per;
+  const int64_t per = (int64_t)D.own_z * D.hxp * D.hy;          // (hxp even: pairs)
+  const int nblk = 3 * D.no, share = gridDim.x / nblk, blk = blockIdx.x / max(share, 1), sub = blockIdx.x - blk * share;   // workgroups per block of the arrays; the remainder idles
   double acc = 0;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) { const int64_t blk = e / per, at = blk * D.co + (e - blk * per); acc = fma(a[at], b[at], acc); }
+  if (share > 0 && blk < nblk) {
+    const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(a + blk * D.co), *__restrict__ b2 = reinterpret_cast<const double2 *>(b + blk * D.co);
+    for (int64_t e = (int64_t)sub * kBlock + threadIdx.x; e < per / 2; e += (int64_t)share * kBlock) { const double2 u = a2[e], v = b2[e]; acc = fma(u.x, v.x, fma(u.y, v.y, acc)); }
+  }
   acc = block_sum(acc, sh);
   store_partial(partials, acc);
 }
@@ -238,10 +242,11 @@ struct OctPass {
   const double *lam_z[3][2]; double cz[3]; const double *bxy;   // mode 1: eigenvalues of the line direction; bxy[(4 c + (o & 3)) pl + column] = the other two directions' share
   int no_shift;                 // log2 of the blocks per component (3: octants, 2: quadrants of the slab form, 0: scalar system)
   int slab_z, chunk0, chunk_total, nchunk;   // slab form, pass 2: workgroup = (local chunk, z parity) of the transposed array; its global chunk number gives (component, quadrant, chunk of the plane)
-  // slab form: the copies around the all-to-alls ride in the passes.  otab (pass 1): entry [block plane position] = where that column lives in the [send | recv] buffer for plane 0
-  // (+ plane * tab_plane; planes >= store_planes belong to the neighbour and are not sent); itab (pass 3): the same for the received planes; row_in (pass 2): offset of every
+  // slab form: the copies around the all-to-alls ride in the passes.  The exchange buffer is [send | recv], each [rank q][plane][share column]; column X = (block) nchunk cw +
+  // plane position belongs to rank q = X / scols, so its address is X + q (pitch - 1) scols + plane scols: pass 1 (slab_io = 1) stores there (planes >= store_planes are the
+  // neighbour's and are not sent; the own share goes straight to the receive half), pass 3 (slab_io = 2) loads the scattered planes from there; pass 2 (row_in): offset of every
   // global plane in the gathered buffer - the block is loaded as even / odd combination of a plane and its mirror image
-  const int64_t *otab, *itab, *row_in; int64_t tab_plane; int store_planes, ng;
+  int slab_io, store_planes, ng, scols, col_unit, rank; float inv_scols; int64_t dest_stride, recv_off; const int64_t *row_in;
   int vec2;                     // rows are 16-byte aligned (even pitch, even chunk offsets): 16-byte block loads; 0: 8-byte loads (the scalar Q1 systems keep their nodal layout)
   const PcgScalars *gate;       // inside a PCG iteration: the launch is a no-op once the solve has finished (the host enqueues iterations ahead of the device-side stopping test)
   unsigned long long *stamps;   // diagnostic (PORO_FDMO_STAMPS): per block 8 words: 100 MHz time at start / block in LDS / GEMM 1 done / intermediate in LDS / GEMM 2 done / stored, HW_ID, XCC_ID
@@ -292,6 +297,19 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   const bool heavy = CORNER && w == (int)(blockIdx.x & (NW - 1));   // this wave also computes tile (XT, XT)
   const int R = P.R, C = MODE == 1 ? min(P.C, P.pl - b * P.C) : P.C;
   const double *__restrict__ T1 = P.T1[c][(o >> P.bit1) & 1] + lane, *__restrict__ T2 = P.T2[c][(o >> P.bit2) & 1] + lane;
+  // slab form: address of plane position `col` of this block in the exchange buffer
+  // (a block's columns lie in at most two shares when a share is at least a block long - up to 12 ranks: the two bases are wave-uniform scalars)
+  int slab_q0 = 0, slab_sw = 0; int64_t slab_base[2] = {0, 0};
+  if (MODE != 1 && P.slab_io) {
+    const int X0 = co * P.col_unit; slab_q0 = X0 / P.scols; slab_sw = (slab_q0 + 1) * P.scols - X0;
+    for (int k = 0; k < 2; ++k) slab_base[k] = (int64_t)X0 + (int64_t)(slab_q0 + k) * P.dest_stride + (int64_t)b * P.scols + ((P.slab_io == 2 || slab_q0 + k == P.rank) ? P.recv_off : 0);
+  }
+  auto slab_at = [&](int col) -> int64_t {
+    if (P.scols >= P.col_unit) return (int64_t)col + (col >= slab_sw ? slab_base[1] : slab_base[0]);
+    const int X = co * P.col_unit + col;
+    int q = (int)((float)X * P.inv_scols); q -= q * P.scols > X; q += (q + 1) * P.scols <= X;      // X / scols (X < 2^24)
+    return (int64_t)X + (int64_t)q * P.dest_stride + (int64_t)b * P.scols + ((P.slab_io == 2 || q == P.rank) ? P.recv_off : 0);
+  };
   auto stamp = [&](int k) { if (P.stamps && tid == 0) P.stamps[(int64_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime(); };
   stamp(0);
   // ---- block -> LDS, zero padded to PADN x PADC (the padding meets zero columns of T, but must be finite).  Rows are 16-byte aligned (even pitch, even chunk
@@ -307,7 +325,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
         const double2 lo = ok ? *reinterpret_cast<const double2 *>(in + P.row_in[rr] + cb) : double2{0.0, 0.0}, hi = (ok && mr != rr) ? *reinterpret_cast<const double2 *>(in + P.row_in[mr] + cb) : double2{0.0, 0.0};
         const bool odd = blockIdx.x & 1;
         stage[u].x = odd ? (mr != rr ? lo.x - hi.x : 0.0) : lo.x + hi.x; stage[u].y = odd ? (mr != rr ? lo.y - hi.y : 0.0) : lo.y + hi.y;
-      } else if (MODE == 2 && P.itab) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + P.itab[(int64_t)co * P.pl + (int64_t)r * P.row_stride + c2] + (int64_t)b * P.tab_plane) : double2{0.0, 0.0};
+      } else if (MODE == 2 && P.slab_io == 2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + slab_at(r * (int)P.row_stride + c2)) : double2{0.0, 0.0};
       else if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
       else { const double *src = in + base + (int64_t)r * P.row_stride + c2; stage[u].x = (e < TOT && r < R && c2 < C) ? src[0] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? src[1] : 0.0; }
     }
@@ -421,7 +439,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = 16 * tr + 4 * q + kq, cc = 16 * tc + j;
-      if (MODE == 0 && P.otab) { if (r < R && cc < C && b < P.store_planes) out[P.otab[(int64_t)co * P.pl + (int64_t)r * P.row_stride + cc] + (int64_t)b * P.tab_plane] = acc[a][q]; }
+      if (MODE == 0 && P.slab_io == 1) { if (r < R && cc < C && b < P.store_planes) out[slab_at(r * (int)P.row_stride + cc)] = acc[a][q]; }
       else if (r < R && cc < C) out[base + (int64_t)r * P.row_stride + cc] = acc[a][q];
     }
   }
@@ -495,13 +513,7 @@ void fdmo_init_slab(FdmOct &O, const int nn[3], const double coef[3][3], int ran
   std::vector<int64_t> rin(S.ng), rout(S.rows_back); std::vector<int32_t> rkz(S.rows_back);
   for (int q = 0; q < N; ++q) for (int k = 0; k < own[q]; ++k) rin[off[q] + k] = S.recv_off + ((int64_t)q * S.max_own + k) * S.scols;
   { int r = 0; for (int q = 0; q < N; ++q) for (int k = 0; k < nl[q]; ++k, ++r) { rout[r] = ((int64_t)q * S.max_nl + k) * S.scols + (q == rank ? S.recv_off : 0); rkz[r] = off[q] + k; } }
-  std::vector<int64_t> otab((size_t)12 * pl), itab((size_t)12 * pl);
-  for (int cq = 0; cq < 12; ++cq) for (int64_t col = 0; col < pl; ++col) {
-    const int b = (int)(col / S.cw), j = (int)(col % S.cw), G = cq * S.nchunk + b, dest = G / S.cps, cl = G % S.cps;
-    otab[(size_t)cq * pl + col] = (dest == rank ? S.recv_off : 0) + (int64_t)dest * S.max_own * S.scols + (int64_t)cl * S.cw + j;
-    itab[(size_t)cq * pl + col] = S.recv_off + (int64_t)dest * S.max_nl * S.scols + (int64_t)cl * S.cw + j;
-  }
-  S.row_in.upload(rin); S.row_out.upload(rout); S.row_kz.upload(rkz); S.otab.upload(otab); S.itab.upload(itab);
+  S.row_in.upload(rin); S.row_out.upload(rout); S.row_kz.upload(rkz);
   S.buf.alloc((size_t)2 * blk * N); S.tz.alloc((size_t)2 * S.cps * S.hzg * S.cw);
   S.buf.zero(s); S.tz.zero(s);
 }
@@ -603,8 +615,8 @@ void fdmo_slab_pass(hipStream_t s, const FdmOct &O, int pass, const double *in, 
   P.mode = first ? 0 : 2; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(first ? hx : hy); P.kk2 = ksteps(first ? hy : hx); P.nblk = nzl; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp;
   P.bit1 = first ? 0 : 1; P.bit2 = first ? 1 : 0;
   for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = first ? O.fwd[c][0][p].p : O.bwd[c][1][p].p; P.T2[c][p] = first ? O.fwd[c][1][p].p : O.bwd[c][0][p].p; }
-  if (first) { P.otab = S.otab.p; P.store_planes = S.own; } else P.itab = S.itab.p;
-  P.tab_plane = S.scols;
+  P.slab_io = first ? 1 : 2; P.store_planes = S.own; P.scols = (int)S.scols; P.inv_scols = 1.0f / (float)S.scols; P.col_unit = S.nchunk * S.cw; P.rank = S.rank;
+  P.dest_stride = (int64_t)((first ? S.max_own : S.max_nl) - 1) * S.scols; P.recv_off = S.recv_off;
   launch_pass_nt(s, nt, P, 12 * P.nblk, in, out, e0, e1);
 }
 static int copy_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
@@ -613,7 +625,7 @@ void fdmo_slab_scatter_pack(hipStream_t s, const FdmOct &O, const PcgScalars *ga
   if (S.my_chunks > 0) hipLaunchKernelGGL(k_fdmo_slab_scatter_pack, copy_grid((int64_t)S.rows_back * S.my_chunks * S.cw), 256, 0, s, G, S.rows_back, S.row_out.p, S.row_kz.p, S.tz.p, S.buf.p, gate);
 }
 void fdmo_dot_owned(hipStream_t s, const FdmOct &O, const double *a, const double *b, double *partials, const PcgScalars *gate) {
-  hipLaunchKernelGGL(k_fdmo_dot_owned, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), a, b, partials, gate);
+  hipLaunchKernelGGL(k_fdmo_dot_owned, std::max(oct_grid(O.co_stride), 3 * O.no), kBlock, 0, s, dims_of(O), a, b, partials, gate);   // (at least one workgroup per block of the arrays)
 }
 
 // ---- the same three sweeps for a SCALAR Q1 system of the box (pressure Jacobian a M + kappa K, projection mass matrix): one "component", no parity octants, the
