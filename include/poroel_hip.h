@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PORO_ABI_VERSION 3   /* 2: poro_solver_opts.omega, PORO_PREC_SSOR / FDM / ILU0, PORO_VEC_STRESS0; 3: poro_solver_opts.stop_rule / poly_degree, poro_constraints, PORO_PREC_FDM and PORO_PREC_CHEBYSHEV for the displacement system, general form of poro_partition, prescribed pressures */
+#define PORO_ABI_VERSION 4   /* 4: poro_desc.tensor (tensor-product grids keep the fast-diagonalisation preconditioners);  2: poro_solver_opts.omega, PORO_PREC_SSOR / FDM / ILU0, PORO_VEC_STRESS0; 3: poro_solver_opts.stop_rule / poly_degree, poro_constraints, PORO_PREC_FDM and PORO_PREC_CHEBYSHEV for the displacement system, general form of poro_partition, prescribed pressures */
 
 /* Reference-cell tables: exactly the numbers the reference pulls out of
  * FEValues / FEFaceValues (PoroElasticDisplacementSolver.h:162-173,
@@ -92,6 +92,16 @@ typedef struct poro_structured {
   double  origin[3];
   double  h[3];
 } poro_structured;
+
+/* Optional: the mesh is a TENSOR-PRODUCT grid - topology and numbering as for a poro_structured box with n[] cells per direction, vertex planes of direction d at
+ * grid[d][0 .. n[d]] (ascending, any spacing), e.g. a graded hyper_rectangle.  The cells are not congruent, so the structured operator kernels do not
+ * apply (the general matrix-free operator runs), but the fast-diagonalisation preconditioners stay exact: their 1D FE matrices are assembled on the
+ * given 1D grids (PORO_PREC_FDM for all three systems; one rank).  Ignored when box.enabled. */
+typedef struct poro_tensor_grid {
+  int32_t enabled;
+  int32_t n[3];
+  const double *grid[3];   /* [n[d] + 1] each */
+} poro_tensor_grid;
 
 /* Partition over ranks.  Slab form for a structured box:  The local mesh is
  * the rank's slab as a standalone box; node planes at the low / high end in the
@@ -164,6 +174,7 @@ typedef struct poro_desc {
   int64_t n_dirichlet_p;
   const int32_t *dirichlet_dof_p;
   const double  *dirichlet_value_p;
+  poro_tensor_grid tensor;
 } poro_desc;
 
 /* Krylov controls.  Reference values: displacement abs 1e-12, 1000 its

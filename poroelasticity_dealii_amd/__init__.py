@@ -49,6 +49,10 @@ class Constraints(C.Structure):
     _fields_ = [("n", C.c_int64), ("dof", _ip), ("ptr", C.POINTER(C.c_int64)), ("master", _ip), ("weight", _dp), ("inhomogeneity", _dp)]
 
 
+class TensorGrid(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("n", C.c_int32 * 3), ("grid", _dp * 3)]
+
+
 class Desc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("dim", C.c_int32), ("degree_u", C.c_int32), ("degree_p", C.c_int32),
                 ("n_cells", C.c_int64), ("n_vertices", C.c_int64), ("n_dofs_u", C.c_int64), ("n_dofs_p", C.c_int64),
@@ -58,7 +62,7 @@ class Desc(C.Structure):
                 ("n_dirichlet", C.c_int64), ("dirichlet_dof", _ip), ("dirichlet_value", _dp),
                 ("n_neumann", C.c_int32), ("neumann_label", _ip), ("neumann_component", _ip), ("neumann_value", _dp),
                 ("mat", Material), ("box", Structured), ("part", Partition), ("cons_u", Constraints), ("cons_p", Constraints),
-                ("n_dirichlet_p", C.c_int64), ("dirichlet_dof_p", _ip), ("dirichlet_value_p", _dp)]
+                ("n_dirichlet_p", C.c_int64), ("dirichlet_dof_p", _ip), ("dirichlet_value_p", _dp), ("tensor", TensorGrid)]
 
 
 class SolverOpts(C.Structure):

@@ -180,6 +180,8 @@ struct poro_ctx {
   int64_t n_cells = 0, n_u = 0, n_p = 0;
   poro_material mat{};
   poro::BoxDev box;
+  // the logical tensor structure the fast-diagonalisation preconditioners work on: the uniform box, or a tensor-product grid without the box tag (poro_desc.tensor)
+  struct Lines { bool on = false, uniform = true; int n[3] = {1, 1, 1}, nn[3] = {1, 1, 1}; std::vector<double> hcell[3]; } lines;
   poro::Comm comm;
   // mesh / dof data
   poro::DevBuf<int32_t> cell_dofs_u, cell_dofs_p, color_cells;
@@ -340,6 +342,7 @@ void fdm_apply(hipStream_t s, const FdmScalar &F, double a, const double k[3], c
 double jacobi_scaled_lambda_max(int n, const std::vector<double> &A);
 double sym_lambda_max(int n, const std::vector<double> &A);   // largest eigenvalue of a small dense symmetric matrix
 void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::vector<double> &S, std::vector<double> &lam);
+void fdmu_eig_1d(int k, const std::vector<double> &cell_sizes, bool fix_lo, bool fix_hi, std::vector<double> &S, std::vector<double> &lam);   // the same on a non-uniform 1D grid
 void fdmu_upload_dir(FdmuDir &D, const std::vector<double> &S, const std::vector<double> &lam, int nn, bool single, bool allow_split);   // D.split tells whether the even / odd form was taken
 // stage 2: the whole application (single rank); 0 / 1: the passes of the leading directions before / after the caller's distributed last direction
 void fdmu_apply(hipStream_t s, const FdmU &F, const double *g, double *z, void *t1, void *t2, int stage);

@@ -20,12 +20,15 @@ namespace poro {
 namespace ctx_detail {
 // ---- fast diagonalisation of the Q1 box operators (kernels_fdm.hip) -------------------------------------------------------------
 bool fdm_p_supported(poro_ctx *c) {
-  if (!c->box.enabled) return false;
+  if (!c->lines.on) return false;
+  if (!c->box.enabled && c->comm.multi()) return false;     // tensor-product grids: one rank
   if (c->comm.multi() && !(c->comm.nccl_comm || (c->comm.ar && c->comm.sr))) return false;
   return true;
 }
-static void upload_dir(FdmDir &D, int n_cells, double h, FdmOct *fused = nullptr, int dir = 0) {
-  std::vector<double> S, lam; q1_eig(n_cells, h, S, lam);
+static void upload_dir(FdmDir &D, const std::vector<double> &hcell, bool uniform, FdmOct *fused = nullptr, int dir = 0) {
+  const int n_cells = (int)hcell.size();
+  std::vector<double> S, lam;
+  if (uniform) q1_eig(n_cells, hcell[0], S, lam); else fdmu_eig_1d(1, hcell, false, false, S, lam);   // (closed form on a uniform line)
   if (fused) fdmo_scalar_upload_dir(*fused, dir, S, lam, n_cells + 1);
   const int n = n_cells + 1;
   std::vector<double> St((size_t)n * n);
@@ -37,10 +40,10 @@ void build_fdm_p(poro_ctx *c) {
   if (!fdm_p_supported(c)) throw Error("PORO_PREC_FDM needs a uniform box (poro_desc.box.enabled) and, when partitioned, an initialised communicator");
   c->fdm_p.dim = c->dim;
   // one rank, 3D, lines of at most 80 nodes: the three-launch form through the block-FDM transform kernel (kernels_fdmo.hip) instead of six single-direction launches
-  int np3[3] = {c->box.n[0] + 1, c->box.n[1] + 1, c->dim == 3 ? c->box.n[2] + 1 : 1};
+  int np3[3] = {c->lines.n[0] + 1, c->lines.n[1] + 1, c->dim == 3 ? c->lines.n[2] + 1 : 1};
   const bool fused = !c->comm.multi() && fdmo_scalar_usable(c->dim, np3) && !std::getenv("PORO_FDM_P_UNFUSED");
   if (fused) fdmo_scalar_init(c->fdm_p_fused, np3, c->stream);
-  for (int d = 0; d < c->dim; ++d) upload_dir(c->fdm_p.dir[d], c->box.n[d], c->box.h[d], fused ? &c->fdm_p_fused : nullptr, d);   // local slab; the last direction is replaced below when partitioned
+  for (int d = 0; d < c->dim; ++d) upload_dir(c->fdm_p.dir[d], c->lines.hcell[d], c->lines.uniform, fused ? &c->fdm_p_fused : nullptr, d);   // local slab; the last direction is replaced below when partitioned
   c->fdm_p_fused.built = fused;
   c->fdm_t1.alloc(c->n_p); c->fdm_t2.alloc(c->n_p);
   if (c->comm.multi()) {
@@ -62,7 +65,7 @@ void build_fdm_p(poro_ctx *c) {
     F.C = (F.ncol_total + N - 1) / N;
     F.max_own = 0; F.max_nl = 0;
     for (int q = 0; q < N; ++q) { F.max_own = std::max(F.max_own, F.layers[q] + (q == N - 1 ? 1 : 0)); F.max_nl = std::max(F.max_nl, F.layers[q] + 1); }
-    upload_dir(F.last, acc, c->box.h[last]);
+    upload_dir(F.last, std::vector<double>((size_t)acc, c->box.h[last]), true);
     const size_t blk = (size_t)std::max(F.max_own, F.max_nl) * F.C;
     F.sendbuf.alloc(blk * N); F.recvbuf.alloc(blk * N); F.tz1.alloc((size_t)F.ng * F.C); F.tz2.alloc((size_t)F.ng * F.C);
     F.sendbuf.zero(c->stream); F.recvbuf.zero(c->stream); F.tz1.zero(c->stream); F.tz2.zero(c->stream);
@@ -152,10 +155,10 @@ void analyse_fdm_u(poro_ctx *c) {
   c->fdm_u_state = -1;
   const bool multi = c->comm.multi();
   if (multi && !(c->comm.nccl_comm || (c->comm.ar && c->comm.sr))) { c->fdm_u_state = 0; c->fdm_u_why = "partitioned context without a communicator yet"; return; }
-  const int dim = c->dim, last = dim - 1; const int64_t nn[3] = {c->box.nn[0], c->box.nn[1], dim == 3 ? c->box.nn[2] : 1};
+  const int dim = c->dim, last = dim - 1; const int64_t nn[3] = {c->lines.nn[0], c->lines.nn[1], dim == 3 ? c->lines.nn[2] : 1};
   std::string why;
   FdmU &F = c->fdm_u;
-  if (!c->box.enabled || !c->interleaved_u) why = "needs a uniform box with node-interleaved displacement dofs";
+  if (!c->lines.on || !c->interleaved_u || (multi && !c->box.enabled)) why = "needs a uniform box (or, on one rank, a tensor-product grid) with node-interleaved displacement dofs";
   else {
     for (int d = 0; d < dim; ++d) if (nn[d] > 4096) why = "more than 4096 nodes per grid line";
   }
@@ -216,10 +219,10 @@ void build_fdm_u(poro_ctx *c) {
   const int dim = c->dim, last = dim - 1, ku = c->k_u;
   const bool multi = c->comm.multi();
   F.dim = dim; F.single = !multi && std::getenv("PORO_FDMU_SINGLE") != nullptr;   // fp32 transforms (experimental switch, one rank)
-  for (int d = 0; d < 3; ++d) F.nn[d] = d < dim ? c->box.nn[d] : 1;
+  for (int d = 0; d < 3; ++d) F.nn[d] = d < dim ? c->lines.nn[d] : 1;
   const double l2g = c->mat.lame_lambda + 2 * c->mat.shear_G, G = c->mat.shear_G;
   for (int comp = 0; comp < dim; ++comp) for (int d = 0; d < dim; ++d) F.coef[comp][d] = d == comp ? l2g : G;
-  int n_cells_last = c->box.n[last];
+  int n_cells_last = c->lines.n[last];
   if (multi) {
     // every rank learns all slab thicknesses through the existing all-reduce
     const int N = std::max(1, c->comm.part.n_ranks), r = c->comm.part.rank;
@@ -257,14 +260,15 @@ void build_fdm_u(poro_ctx *c) {
   for (int d = 0; d < dim; ++d) {
     std::vector<double> S[4], lam[4]; bool have[4] = {false, false, false, false};
     const bool global_dir = multi && d == last;
-    const int ncell = global_dir ? n_cells_last : c->box.n[d], nnode = ku * ncell + 1;
+    const int ncell = global_dir ? n_cells_last : c->lines.n[d], nnode = ku * ncell + 1;
+    const std::vector<double> hcell = global_dir ? std::vector<double>((size_t)ncell, c->box.h[d]) : c->lines.hcell[d];
     bool allow_split = true;
     for (int comp = 0; comp < dim; ++comp) allow_split = allow_split && F.fix[comp][d][0] == F.fix[comp][d][1];
     for (int attempt = 0; attempt < 2; ++attempt) {
       bool all_split = true;
       for (int comp = 0; comp < dim; ++comp) {
         const int key = F.fix[comp][d][0] * 2 + F.fix[comp][d][1];
-        if (!have[key]) { fdmu_eig_1d(ku, ncell, c->box.h[d], F.fix[comp][d][0], F.fix[comp][d][1], S[key], lam[key]); have[key] = true; }
+        if (!have[key]) { fdmu_eig_1d(ku, hcell, F.fix[comp][d][0], F.fix[comp][d][1], S[key], lam[key]); have[key] = true; }
         FdmuDir &D = global_dir ? F.last_global[comp] : F.dir[comp][d];
         fdmu_upload_dir(D, S[key], lam[key], nnode, global_dir ? false : F.single, allow_split);
         all_split = all_split && D.split;

@@ -141,13 +141,15 @@ void setup(poro_ctx *c, const poro_desc *d) {
   if (d->part.n_neighbours > 0 && d->box.enabled) throw Error("a general partition (poro_partition.n_neighbours > 0) carries no box tag: pieces are not boxes");
   if (!d->box.enabled && d->part.n_ranks > 1 && d->part.n_neighbours <= 0) throw Error("a partitioned general mesh needs the interface lists of poro_partition (n_neighbours > 0)");
   setup_general_partition(c, d);
-  if (d->box.enabled) {
-    // the lexicographic numbering the structured kernels assume must be the caller's numbering (spot-checked on three cells)
+  if (d->tensor.enabled && !d->box.enabled && (d->part.n_ranks > 1 || d->cons_u.n || d->cons_p.n)) throw Error("poro_desc.tensor: one rank, no constraint lists");
+  if (d->box.enabled || d->tensor.enabled) {
+    // the lexicographic numbering the structured kernels / the fast diagonalisation assume must be the caller's numbering (spot-checked on three cells)
+    const int32_t *bn = d->box.enabled ? d->box.n : d->tensor.n;
     int64_t nn[3] = {1, 1, 1}, np[3] = {1, 1, 1}, ncells = 1;
-    for (int k = 0; k < c->dim; ++k) { if (d->box.n[k] < 1) throw Error("box.n must be positive"); nn[k] = (int64_t)c->k_u * d->box.n[k] + 1; np[k] = (int64_t)d->box.n[k] + 1; ncells *= d->box.n[k]; }
+    for (int k = 0; k < c->dim; ++k) { if (bn[k] < 1) throw Error("box.n must be positive"); nn[k] = (int64_t)c->k_u * bn[k] + 1; np[k] = (int64_t)bn[k] + 1; ncells *= bn[k]; }
     if (nn[0] * nn[1] * nn[2] * c->dim != c->n_u || np[0] * np[1] * np[2] != c->n_p || ncells != c->n_cells) throw Error("box does not match n_dofs_u / n_dofs_p / n_cells");
     const int n1 = c->k_u + 1;
-    const int64_t ncx = d->box.n[0], ncy = d->box.n[1];
+    const int64_t ncx = bn[0], ncy = bn[1];
     for (int64_t cell : {(int64_t)0, c->n_cells / 2, c->n_cells - 1}) {
       const int64_t ci = cell % ncx, cj = (cell / ncx) % ncy, ck = cell / (ncx * ncy);
       for (int sidx = 0; sidx < c->ns_u; ++sidx) {
@@ -165,6 +167,17 @@ void setup(poro_ctx *c, const poro_desc *d) {
   if (const char *v = std::getenv("PORO_MF_VARIANT")) c->mf_variant = (std::string(v) == "gather" || std::string(v) == "0") ? 0 : 1;
   c->box.enabled = d->box.enabled;
   for (int k = 0; k < 3; ++k) { c->box.n[k] = d->box.enabled && k < c->dim ? d->box.n[k] : 1; c->box.h[k] = d->box.h[k]; c->box.nn[k] = c->k_u * c->box.n[k] + 1; }
+  if (d->box.enabled || d->tensor.enabled) {
+    c->lines.on = true; c->lines.uniform = d->box.enabled != 0;
+    for (int k = 0; k < 3; ++k) {
+      const int n = k < c->dim ? (d->box.enabled ? d->box.n[k] : d->tensor.n[k]) : 1;
+      c->lines.n[k] = n; c->lines.nn[k] = c->k_u * n + 1; c->lines.hcell[k].assign((size_t)n, d->box.enabled ? d->box.h[k] : 1.0);
+      if (!d->box.enabled && k < c->dim) {
+        if (!d->tensor.grid[k]) throw Error("poro_desc.tensor.grid missing");
+        for (int i = 0; i < n; ++i) { const double h = d->tensor.grid[k][i + 1] - d->tensor.grid[k][i]; if (!(h > 0)) throw Error("poro_desc.tensor.grid must be strictly ascending"); c->lines.hcell[k][i] = h; }
+      }
+    }
+  }
 
   // tables -> one device buffer
   std::vector<double> T; std::vector<size_t> off;

@@ -726,13 +726,14 @@ void householder_ql_eig(int n, std::vector<double> &A, std::vector<double> &V, s
 }
 
 // FE_Q(k) mass / stiffness matrices of n_cells cells of length h (dense, nn = k n_cells + 1); element matrices as in kernels_kron.hip
-void fe1d(int k, int n_cells, double h, std::vector<double> &M, std::vector<double> &K) {
-  const int nn = k * n_cells + 1; M.assign((size_t)nn * nn, 0.0); K.assign((size_t)nn * nn, 0.0);
+void fe1d(int k, const std::vector<double> &hc, std::vector<double> &M, std::vector<double> &K) {
+  const int n_cells = (int)hc.size(), nn = k * n_cells + 1; M.assign((size_t)nn * nn, 0.0); K.assign((size_t)nn * nn, 0.0);
   static const double M2[3][3] = {{4, 2, -1}, {2, 16, 2}, {-1, 2, 4}}, K2[3][3] = {{7, -8, 1}, {-8, 16, -8}, {1, -8, 7}};
   static const double M1[2][2] = {{2, 1}, {1, 2}}, K1[2][2] = {{1, -1}, {-1, 1}};
   for (int c = 0; c < n_cells; ++c)
     for (int a = 0; a <= k; ++a) for (int b = 0; b <= k; ++b) {
       const size_t at = (size_t)(k * c + a) * nn + (k * c + b);
+      const double h = hc[c];
       if (k == 2) { M[at] += h / 30.0 * M2[a][b]; K[at] += K2[a][b] / (3.0 * h); } else { M[at] += h / 6.0 * M1[a][b]; K[at] += K1[a][b] / h; }
     }
 }
@@ -742,7 +743,11 @@ void fe1d(int k, int n_cells, double h, std::vector<double> &M, std::vector<doub
 // generalised eigenpairs K s = lam M s of the 1D FE_Q(k) matrices with the end nodes lo / hi removed when fix_lo / fix_hi:
 // S (nn x nn row-major, S^T M S = I on the free block, zero rows for removed nodes, zero columns behind the n_free modes), lam (inf behind n_free)
 void fdmu_eig_1d(int k, int n_cells, double h, bool fix_lo, bool fix_hi, std::vector<double> &S, std::vector<double> &lam) {
-  std::vector<double> M, K; fe1d(k, n_cells, h, M, K);
+  fdmu_eig_1d(k, std::vector<double>((size_t)n_cells, h), fix_lo, fix_hi, S, lam);
+}
+void fdmu_eig_1d(int k, const std::vector<double> &hc, bool fix_lo, bool fix_hi, std::vector<double> &S, std::vector<double> &lam) {
+  const int n_cells = (int)hc.size();
+  std::vector<double> M, K; fe1d(k, hc, M, K);
   const int nn = k * n_cells + 1, f0 = fix_lo ? 1 : 0, nf = nn - f0 - (fix_hi ? 1 : 0);
   S.assign((size_t)nn * nn, 0.0); lam.assign(nn, std::numeric_limits<double>::infinity());
   if (nf <= 0) return;

@@ -340,6 +340,7 @@ struct ProblemData {
   std::vector<int64_t> part_ptr_u, part_ptr_p;
   bool ties_added = false;
   bool dirichlet_given = false;       // the Dirichlet list was filled by the caller (pieces of a partition: from the global list)
+  std::vector<double> tensor_grid[3]; // vertex planes per direction of a tensor-product grid without the box tag (graded boxes)
   poro_desc d{};
 
   // ConstraintMatrix semantics of PoroElasticDisplacementSolver.h:112-136: hanging-node constraints first, boundary values only for dofs that are
@@ -456,6 +457,13 @@ inline void build_graded_box_problem(ProblemData &P, int dim, const int n[3], co
   P.part.rank = 0; P.part.n_ranks = 1; P.part.has_lower = 0; P.part.has_upper = 0; P.part.plane_u = 0; P.part.plane_p = 0;
   P.finalize(k_u);            // (the dofs keep the lexicographic numbering of the box)
   P.d.box.enabled = 0;        // ... but the descriptor carries no box tag: the cells are not congruent
+  // what is left of the structure: a tensor-product grid (the fast-diagonalisation preconditioners stay exact on it)
+  P.d.tensor = poro_tensor_grid{}; P.d.tensor.enabled = 1;
+  for (int d = 0; d < 3; ++d) {
+    P.d.tensor.n[d] = d < dim ? n[d] : 1; P.tensor_grid[d].assign((size_t)P.d.tensor.n[d] + 1, 0.0);
+    if (d < dim) for (int i = 0; i <= n[d]; ++i) { const double g = grading[d], t = (double)i / n[d]; P.tensor_grid[d][i] = g != 0.0 ? origin[d] + size[d] * std::expm1(g * t) / std::expm1(g) : origin[d] + size[d] * t; }
+    P.d.tensor.grid[d] = P.tensor_grid[d].data();
+  }
 }
 
 inline void build_refined_box_problem(ProblemData &P, int dim, const int n[3], const double size[3], int k_u, const int lo[3], const int hi[3]) {

@@ -22,7 +22,7 @@ def test_c_abi_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     L.poro_abi_version.restype = C.c_int
-    assert L.poro_abi_version() == 3
+    assert L.poro_abi_version() == 4
 
 
 def test_product_fails_loudly_without_a_gpu():

@@ -92,3 +92,45 @@ def test_graded_box_sum_factorised_operator(deg, n, grading, monkeypatch):
         assert rc == 0 and np.linalg.norm(F.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
     finally:
         F.close(); O.close(); P.close()
+
+
+@pytest.mark.parametrize("deg,n,grading", [(2, (6, 5, 4), (1.5, 0.0, -1.0)), (1, (7, 6, 8), (2.0, 1.0, 0.5)), (2, (6, 6, 6), (0.0, 0.0, 0.0))], ids=str)
+def test_graded_box_keeps_the_fast_diagonalisation(deg, n, grading):
+    """poro_desc.tensor: on a tensor-product grid without the box tag the fast-diagonalisation preconditioners stay EXACT for the blocks they invert (1D FE matrices on the
+    graded 1D grids): the pressure Jacobian and the projection mass matrix are solved in 1-2 CG iterations, the displacement system in a number of iterations that does
+    not depend on the grading; the solutions are the oracle's (Jacobi-CG on the assembled matrices)"""
+    from common import BC_3D, material
+    P = pk.Problem.graded_box(3, list(n), [10.0] * 3, deg, material(), BC_3D, list(grading))
+    U = pk.Problem.graded_box(3, list(n), [10.0] * 3, deg, material(), BC_3D, [0.0] * 3)
+    assert not P.desc.box.enabled and P.desc.tensor.enabled and list(P.desc.tensor.n) == list(n)
+    O = oracle_py.Oracle(P, hoisted=True)
+    F, G = pk.Context(P, 0, pk.OP_MATRIX_FREE), pk.Context(U, 0, pk.OP_MATRIX_FREE)
+    try:
+        assert F.supports_preconditioner(0, pk.PREC_FDM) and F.supports_preconditioner(1, pk.PREC_FDM)
+        synth = lambda m, ph=0.0: np.sin(0.37 * np.arange(m) + ph)   # noqa: E731
+        p = REF["p_init"] * (1 + 0.2 * synth(F.n_p))
+        for S in (F, G, O):
+            S.set(pk.VEC_P, p); S.disp_assemble_system(True)
+        assert O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=20000)[0] == 0
+        rc, info = F.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=200, prec=pk.PREC_FDM)
+        rcu, infou = G.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=200, prec=pk.PREC_FDM)
+        assert rc == 0 and rcu == 0 and np.linalg.norm(F.get(pk.VEC_U) - O.get(pk.VEC_U)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_U))
+        assert info.iterations <= infou.iterations + 8, (info.iterations, infou.iterations)   # block-diagonal preconditioning: the count follows the material, not the mesh
+        # pressure Jacobian a M + kappa K and the projection mass matrix: inverted exactly
+        n = F.n_p
+        vals = {pk.VEC_P_OLD: 10e6 * (1 + 0.05 * synth(n, 0.2)), pk.VEC_EPSV: -2e-6 * (1 + 0.3 * synth(n, 0.5)), pk.VEC_EPSV0: -2e-6 * np.ones(n)}
+        for S in (F, O):
+            for k, v in vals.items():
+                S.set(k, v)
+            S.pres_assemble_residual(60.0); S.pres_assemble_jacobian(60.0)
+        rc0, _ = O.pres_solve(rel_tol=1e-13); rc, info = F.pres_solve(rel_tol=1e-8, prec=pk.PREC_FDM)
+        assert rc0 == 0 and rc == 0 and info.iterations <= 2, info.iterations
+        assert np.linalg.norm(F.get(pk.VEC_DP) - O.get(pk.VEC_DP)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_DP))
+        for S in (F, O):
+            S.proj_assemble_matrix(); S.proj_assemble_rhs([0, 4, 8])
+        for e in (0, 3, 5):
+            rc0, _ = O.proj_solve(e, rel_tol=1e-13); rc, info = F.proj_solve(e, rel_tol=1e-8, prec=pk.PREC_FDM)
+            assert rc0 == 0 and rc == 0 and info.iterations <= 2, info.iterations
+            assert np.linalg.norm(F.get(pk.VEC_STRAIN0 + e) - O.get(pk.VEC_STRAIN0 + e)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_STRAIN0 + e))
+    finally:
+        F.close(); G.close(); O.close(); P.close(); U.close()
