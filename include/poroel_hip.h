@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PORO_ABI_VERSION 4   /* 4: poro_desc.tensor (tensor-product grids keep the fast-diagonalisation preconditioners);  2: poro_solver_opts.omega, PORO_PREC_SSOR / FDM / ILU0, PORO_VEC_STRESS0; 3: poro_solver_opts.stop_rule / poly_degree, poro_constraints, PORO_PREC_FDM and PORO_PREC_CHEBYSHEV for the displacement system, general form of poro_partition, prescribed pressures */
+#define PORO_ABI_VERSION 4   /* 4: poro_desc.tensor (tensor-product grids keep the fast-diagonalisation preconditioners), poro_desc.coarse + PORO_PREC_TWO_LEVEL;  2: poro_solver_opts.omega, PORO_PREC_SSOR / FDM / ILU0, PORO_VEC_STRESS0; 3: poro_solver_opts.stop_rule / poly_degree, poro_constraints, PORO_PREC_FDM and PORO_PREC_CHEBYSHEV for the displacement system, general form of poro_partition, prescribed pressures */
 
 /* Reference-cell tables: exactly the numbers the reference pulls out of
  * FEValues / FEFaceValues (PoroElasticDisplacementSolver.h:162-173,
@@ -102,6 +102,19 @@ typedef struct poro_tensor_grid {
   int32_t n[3];
   const double *grid[3];   /* [n[d] + 1] each */
 } poro_tensor_grid;
+
+/* Optional coarse space for the two-level preconditioner of the displacement system (PORO_PREC_TWO_LEVEL): the mesh is a refinement of a uniform box - a locally
+ * refined hyper_rectangle (refine_mesh, PoroelasticityFSS.h:447-498) - whose own description is `box_problem` (same material and boundary conditions, box tag
+ * set; it must stay alive until poro_ctx_create has returned), and every displacement NODE i of this mesh (= dof / dim: the numbering must be node-interleaved)
+ * interpolates the box's FE functions: v_h(node i) = sum_k weight[k] * v_H(node[k]), k in ptr[i] .. ptr[i+1].  One rank. */
+struct poro_desc;
+typedef struct poro_coarse_space {
+  int32_t enabled;
+  const struct poro_desc *box_problem;
+  const int64_t *ptr;       /* [n_dofs_u / dim + 1] */
+  const int32_t *node;      /* [ptr[last]] coarse node numbers */
+  const double  *weight;
+} poro_coarse_space;
 
 /* Partition over ranks.  Slab form for a structured box:  The local mesh is
  * the rank's slab as a standalone box; node planes at the low / high end in the
@@ -175,6 +188,7 @@ typedef struct poro_desc {
   const int32_t *dirichlet_dof_p;
   const double  *dirichlet_value_p;
   poro_tensor_grid tensor;
+  poro_coarse_space coarse;
 } poro_desc;
 
 /* Krylov controls.  Reference values: displacement abs 1e-12, 1000 its
@@ -210,8 +224,11 @@ enum { PORO_STOP_RHS = 0, PORO_STOP_REDUCTION = 1 };
  * count drops by about the degree + 1 while the operator applications of the polynomial need no dot products and, on 3D boxes, no vector kernels either
  * (the update z_{j+1} = z_j + D^-1 (g - A z_j) / r_j - roots r_j of the shifted Chebyshev polynomial - is applied inside the structured operator kernel where the product leaves the registers): fewer bytes and far fewer reductions per
  * operator application than Jacobi-CG.  lambda_max(D^-1 A) comes from the Lanczos tridiagonal of 25 Jacobi-CG steps when the matrix is (re)built (+5 %,
- * capped on uniform boxes by the rigorous element bound lambda_max(diag(K_e)^-1 K_e)). */
-enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3, PORO_PREC_ILU0 = 4, PORO_PREC_CHEBYSHEV = 5 };
+ * capped on uniform boxes by the rigorous element bound lambda_max(diag(K_e)^-1 K_e)).
+ * PORO_PREC_TWO_LEVEL (displacement system; meshes with poro_desc.coarse, i.e. locally refined boxes with their hanging-node constraints) = additive two-level
+ * preconditioner z = omega D^-1 g + P B_H^-1 P^T g: Jacobi on the refined mesh plus the BLOCK fast diagonalisation of the underlying uniform box as coarse solve (P = the
+ * FE interpolation of poro_coarse_space).  The CG iteration count stays bounded under uniform refinement of the whole configuration. */
+enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3, PORO_PREC_ILU0 = 4, PORO_PREC_CHEBYSHEV = 5, PORO_PREC_TWO_LEVEL = 6 };
 enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };
 enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_JACOBIAN_P = 3 };
 enum { PORO_VEC_U = 0, PORO_VEC_RHS_U = 1, PORO_VEC_P = 2, PORO_VEC_P_OLD = 3, PORO_VEC_DP = 4,

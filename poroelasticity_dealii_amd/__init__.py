@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
 # ids of include/poroel_hip.h
-PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM, PREC_ILU0, PREC_CHEBYSHEV = 0, 1, 2, 3, 4, 5
+PREC_NONE, PREC_JACOBI, PREC_SSOR, PREC_FDM, PREC_ILU0, PREC_CHEBYSHEV, PREC_TWO_LEVEL = 0, 1, 2, 3, 4, 5, 6
 STOP_RHS, STOP_REDUCTION = 0, 1
 OP_CSR, OP_MATRIX_FREE = 0, 1
 MAT_A_U, MAT_MASS_P, MAT_LAPLACE_P, MAT_JACOBIAN_P = 0, 1, 2, 3
@@ -53,6 +53,10 @@ class TensorGrid(C.Structure):
     _fields_ = [("enabled", C.c_int32), ("n", C.c_int32 * 3), ("grid", _dp * 3)]
 
 
+class CoarseSpace(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("box_problem", C.c_void_p), ("ptr", C.POINTER(C.c_int64)), ("node", _ip), ("weight", _dp)]
+
+
 class Desc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("dim", C.c_int32), ("degree_u", C.c_int32), ("degree_p", C.c_int32),
                 ("n_cells", C.c_int64), ("n_vertices", C.c_int64), ("n_dofs_u", C.c_int64), ("n_dofs_p", C.c_int64),
@@ -62,7 +66,7 @@ class Desc(C.Structure):
                 ("n_dirichlet", C.c_int64), ("dirichlet_dof", _ip), ("dirichlet_value", _dp),
                 ("n_neumann", C.c_int32), ("neumann_label", _ip), ("neumann_component", _ip), ("neumann_value", _dp),
                 ("mat", Material), ("box", Structured), ("part", Partition), ("cons_u", Constraints), ("cons_p", Constraints),
-                ("n_dirichlet_p", C.c_int64), ("dirichlet_dof_p", _ip), ("dirichlet_value_p", _dp), ("tensor", TensorGrid)]
+                ("n_dirichlet_p", C.c_int64), ("dirichlet_dof_p", _ip), ("dirichlet_value_p", _dp), ("tensor", TensorGrid), ("coarse", CoarseSpace)]
 
 
 class SolverOpts(C.Structure):

@@ -215,6 +215,9 @@ struct poro_ctx {
   poro::DevBuf<double> cheb_z, cheb_t;
   poro::FdmOct fdm_oct;
   poro::FdmOct fdm_p_fused;          // the scalar Q1 systems through the same transform kernel (3D boxes, one rank, lines of <= 80 nodes)
+  // two-level preconditioner (poro_desc.coarse): the underlying uniform box as a context of its own (same device and stream) + the node-wise interpolation P and its transpose
+  struct TwoLevel { poro_ctx *box = nullptr; int64_t n_fine = 0, n_coarse = 0; poro::DevBuf<int64_t> p_ptr, pt_ptr; poro::DevBuf<int32_t> p_col, pt_col; poro::DevBuf<double> p_w, pt_w; } two_level;
+  bool borrowed_stream = false;     // (the box context of a two-level preconditioner runs on its parent's stream)
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
   std::vector<uint8_t> h_node_mask;
   poro::DevBuf<double> partials; poro::DevBuf<poro::PcgScalars> scal; poro::DevBuf<double> red;   // red: kScalarSlots doubles
@@ -238,6 +241,10 @@ namespace poro {
 // ---- kernels_la.hip -----------------------------------------------------------------------------
 void la_fill(hipStream_t s, double *x, double v, int64_t n);
 // copy n <= 16 doubles from `src` (device) and optionally *sc into the host mailbox, then publish sequence number `seq` (system-scope release)
+// node-wise sparse interpolation of a node-interleaved vector: out[(row, c)] = sum_k w[k] in[(col[k], c)] (prolongation by P, restriction by its transpose)
+void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out);
+// z = omega D^-1 g + P z_c, zero on the inert dofs (additive two-level preconditioner)
+void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z);
 void la_post(hipStream_t s, Mailbox *mb, unsigned long long seq, const double *src, int n, const PcgScalars *sc);
 void la_copy(hipStream_t s, double *y, const double *x, int64_t n);
 void la_axpy(hipStream_t s, double *y, double a, const double *x, int64_t n);

@@ -43,6 +43,18 @@ int poro_ctx_create(const poro_desc *desc, int device, int operator_mode, poro_c
     kron_prepare_device();   // function attributes are per device: opt in to the large dynamic LDS on THIS one
     { void *mbp = nullptr; PORO_HIP(hipHostMalloc(&mbp, sizeof(Mailbox), hipHostMallocDefault)); std::memset(mbp, 0, sizeof(Mailbox)); c->mailbox = static_cast<Mailbox *>(mbp); }
     setup(c.get(), desc);
+    if (desc->coarse.enabled) {
+      // two-level preconditioner: the underlying uniform box becomes a context of its own on this context's stream
+      if (!desc->coarse.box_problem || !desc->coarse.ptr || !desc->coarse.node || !desc->coarse.weight) throw Error("poro_desc.coarse: box_problem / ptr / node / weight missing");
+      if (!desc->coarse.box_problem->box.enabled || desc->coarse.box_problem->coarse.enabled) throw Error("poro_desc.coarse.box_problem must be a uniform box (box.enabled) without a coarse space of its own");
+      if (desc->coarse.box_problem->dim != desc->dim || desc->coarse.box_problem->degree_u != desc->degree_u) throw Error("poro_desc.coarse.box_problem: dimension / degree differ");
+      if (!c->interleaved_u || c->comm.multi()) throw Error("poro_desc.coarse needs node-interleaved displacement dofs on one rank");
+      poro_ctx *box = nullptr;
+      if (poro_ctx_create(desc->coarse.box_problem, device, PORO_OP_MATRIX_FREE, &box) != 0) throw Error(std::string("poro_desc.coarse.box_problem: ") + poro_last_error());
+      PORO_HIP(hipStreamSynchronize(box->stream)); (void)hipStreamDestroy(box->stream); box->stream = c->stream; box->borrowed_stream = true;
+      c->two_level.box = box;
+      setup_two_level(c.get(), desc);
+    }
     *out = c.release();
     return 0;
   });
@@ -55,7 +67,8 @@ void poro_ctx_destroy(poro_ctx *c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   c->event_pool.clear();
   if (c->comm.nccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->comm.nccl_comm);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->two_level.box) { poro_ctx_destroy(c->two_level.box); c->two_level.box = nullptr; }
+  if (c->stream && !c->borrowed_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -275,7 +288,8 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
 int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec) {
   if (!c) return 0;
   if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
-  if (which_system == 0 && c->cons_u.n) return prec == PORO_PREC_CHEBYSHEV;      // condensed operators exist at operator level only: Jacobi and the polynomial built on it
+  if (prec == PORO_PREC_TWO_LEVEL) return which_system == 0 && two_level_supported(c);
+  if (which_system == 0 && c->cons_u.n) return prec == PORO_PREC_CHEBYSHEV;      // condensed operators exist at operator level only: Jacobi, the polynomial built on it, the two-level form above
   if (which_system == 1 && (c->cons_p.n || c->n_pdir)) return 0;
   if (prec == PORO_PREC_SSOR || prec == PORO_PREC_ILU0) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
   if (prec == PORO_PREC_CHEBYSHEV) return which_system == 0;
@@ -288,8 +302,8 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
     PORO_HIP(hipSetDevice(c->device));
     if (!c->matrix_built) throw Error("disp_solve before disp_assemble_system");
     const int mode = c->operator_mode;
-    if (c->cons_u.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE && opts->preconditioner != PORO_PREC_CHEBYSHEV)
-      throw Error("meshes with constraint lists: PORO_PREC_JACOBI / CHEBYSHEV / NONE only (the operator is condensed on the fly)");
+    if (c->cons_u.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE && opts->preconditioner != PORO_PREC_CHEBYSHEV && opts->preconditioner != PORO_PREC_TWO_LEVEL)
+      throw Error("meshes with constraint lists: PORO_PREC_JACOBI / CHEBYSHEV / TWO_LEVEL / NONE only (the operator is condensed on the fly)");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       if (mode != PORO_OP_CSR) throw Error("PORO_PREC_ILU0 needs the assembled CSR operator");
       const int rc = pcg_ilu0(c, c->Au, c->Au_val.p, c->ilu_u, c->ilu_u_valid, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info);
@@ -444,6 +458,18 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       DiagVec dz; dz.full = c->dinv_u.p; dz.ncomp = c->dim; dz.inert = c->dir_mask.p; dz.z = c->wz_u.p;
       const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_fdm_u, oct != nullptr /* every launch of an iteration is gated: overshooting is cheap */, oct);
       la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
+      return rc;
+    }
+    if (opts->preconditioner == PORO_PREC_TWO_LEVEL) {
+      // z = omega D^-1 g + P B_H^-1 P^T g: Jacobi on this mesh + the block fast diagonalisation of the underlying uniform box; SolverCG's recurrence with an explicit preconditioner vector
+      if (!two_level_supported(c)) throw Error("PORO_PREC_TWO_LEVEL needs poro_desc.coarse (a refinement of a uniform box whose Dirichlet conditions cover whole faces)");
+      const double om = opts->omega > 0 ? opts->omega : 1.0;
+      if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { two_level_precondition_u(c, g, z, om); return false; };
+      DiagVec dz; dz.full = c->dinv_u.p; dz.ncomp = c->dim; dz.inert = c->cons_u.inert.p; dz.z = c->wz_u.p;
+      const int rc = pcg(c, apply, c->n_u, c->comm.part.plane_u, vec(c, PORO_VEC_U), vec(c, PORO_VEC_RHS_U), dz, c->wg_u.p, c->wd_u.p, c->wh_u.p, opts, info, &P, c->pcg_hint_u);
+      la_set_constrained(c->stream, vec(c, PORO_VEC_U), c->dir_mask.p, c->dir_val.p, c->n_u);
+      la_cons_expand(c->stream, c->cons_u, vec(c, PORO_VEC_U), true);
       return rc;
     }
     DiagVec dv; dv.full = c->dinv_u.p; dv.ncomp = c->dim; dv.inert = c->cons_u.inert.p;

@@ -296,6 +296,39 @@ void fdm_precondition_u_slab(poro_ctx *c, const double *g, double *z, const PcgS
   alltoall_blocks(c, send, recv, (int64_t)S.max_nl * S.scols, true);
   fdmo_slab_pass(s, O, 3, S.buf.p, z, gate);                                          // y, x backward, reading the received planes in place
 }
+// ---- additive two-level preconditioner on refinements of a uniform box (poro_desc.coarse) ----------------------------------------------------
+void setup_two_level(poro_ctx *c, const poro_desc *d) {
+  auto &T = c->two_level; const int dim = c->dim;
+  T.n_fine = c->n_u / dim; T.n_coarse = T.box->n_u / dim;
+  const int64_t nnz = d->coarse.ptr[T.n_fine];
+  std::vector<int64_t> tp((size_t)T.n_coarse + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) { const int32_t j = d->coarse.node[k]; if (j < 0 || j >= T.n_coarse) throw Error("poro_desc.coarse.node out of range"); tp[j + 1]++; }
+  for (int64_t j = 0; j < T.n_coarse; ++j) tp[j + 1] += tp[j];
+  std::vector<int32_t> tc((size_t)nnz); std::vector<double> tw((size_t)nnz); std::vector<int64_t> pos(tp.begin(), tp.end() - 1);
+  for (int64_t i = 0; i < T.n_fine; ++i) {
+    if (d->coarse.ptr[i + 1] < d->coarse.ptr[i]) throw Error("poro_desc.coarse.ptr not monotone");
+    for (int64_t k = d->coarse.ptr[i]; k < d->coarse.ptr[i + 1]; ++k) { const int64_t at = pos[d->coarse.node[k]]++; tc[at] = (int32_t)i; tw[at] = d->coarse.weight[k]; }
+  }
+  T.p_ptr.upload(d->coarse.ptr, (size_t)T.n_fine + 1); T.p_col.upload(d->coarse.node, (size_t)nnz); T.p_w.upload(d->coarse.weight, (size_t)nnz);
+  T.pt_ptr.upload(tp); T.pt_col.upload(tc); T.pt_w.upload(tw);
+}
+bool two_level_supported(poro_ctx *c) {
+  if (!c->two_level.box) return false;
+  analyse_fdm_u(c->two_level.box);
+  return c->two_level.box->fdm_u_state == 1;
+}
+void two_level_precondition_u(poro_ctx *c, const double *g, double *z, double omega) {
+  Timed tm(c, "precondition_u_two_level");
+  auto &T = c->two_level; poro_ctx *H = T.box; hipStream_t s = c->stream; const int dim = c->dim;
+  build_fdm_u(H);
+  double *rc = H->wg_u.p, *zc = H->wz_u.p;                                  // the box context's work vectors (it never solves anything itself)
+  la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, dim, g, rc);              // r_H = P^T g
+  FdmOct &O = H->fdm_oct;
+  if (O.built) { fdmo_from_nodal(s, O, rc, O.g.p); fdmo_apply(s, O, O.g.p, O.z.p, O.t.p); fdmo_to_nodal(s, O, O.z.p, zc); }
+  else fdm_precondition_u(H, rc, zc);                                         // z_H = blockdiag(A_H)^-1 r_H (zero on the box's Dirichlet faces)
+  la_two_level_combine(s, T.p_ptr.p, T.p_col.p, T.p_w.p, T.n_fine, dim, zc, g, c->dinv_u.p, c->cons_u.inert.p, omega, z);
+}
+
 void fdm_precondition_u(poro_ctx *c, const double *g, double *z) {
   Timed tm(c, "precondition_u_fdm");
   hipStream_t s = c->stream; FdmU &F = c->fdm_u;

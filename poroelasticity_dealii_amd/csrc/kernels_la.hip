@@ -382,6 +382,22 @@ template <class F> void dispatch_lanes(int L, F &&f) {
 
 }  // namespace
 
+__global__ void __launch_bounds__(kBlock) k_nodal_interp(const int64_t *__restrict__ ptr, const int32_t *__restrict__ col, const double *__restrict__ w, int64_t n_rows, int ncomp, const double *__restrict__ in, double *__restrict__ out,
+                                                       const double *__restrict__ g, const double *__restrict__ dinv, const uint8_t *__restrict__ inert, double omega) {
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n_rows * ncomp; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = t / ncomp; const int c = (int)(t - row * ncomp);
+    double acc = 0;
+    for (int64_t k = ptr[row]; k < ptr[row + 1]; ++k) acc = fma(w[k], in[(int64_t)col[k] * ncomp + c], acc);
+    if (g) acc = (inert && inert[t]) ? 0.0 : fma(omega * dinv[t], g[t], acc);
+    out[t] = acc;
+  }
+}
+void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out) {
+  if (n_rows) hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, (const double *)nullptr, (const double *)nullptr, (const uint8_t *)nullptr, 0.0);
+}
+void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z) {
+  if (n_rows) hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, zc, z, g, dinv, inert, omega);
+}
 void la_post(hipStream_t s, Mailbox *mb, unsigned long long seq, const double *src, int n, const PcgScalars *sc) { hipLaunchKernelGGL(k_post, 1, 64, 0, s, mb, seq, src, n, sc); }
 void la_fill(hipStream_t s, double *x, double v, int64_t n) { if (n) hipLaunchKernelGGL(k_fill, grid_for(n), kBlock, 0, s, x, v, n); }
 // device-to-device copy as a kernel: hipMemcpyAsync costs the host ~50 us per call (measured between the back-to-back copies of poro_state_restore), a launch ~5 us

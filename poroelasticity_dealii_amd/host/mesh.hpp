@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -228,6 +229,8 @@ struct ConstraintList {
 // from the face interpolation matrices of FE_Q).
 struct RefinedBox {
   Mesh mesh; DoFs dofs; ConstraintList cons_u, cons_p;
+  // interpolation from the underlying uniform box: displacement node i = sum of weight * box node (lexicographic box numbering), rows by prol_ptr
+  std::vector<int64_t> prol_ptr; std::vector<int32_t> prol_node; std::vector<double> prol_w;
 };
 inline RefinedBox make_refined_box(int dim, const int n[3], const double origin[3], const double h[3], int k_u, const int lo[3], const int hi[3]) {
   RefinedBox R; Mesh &m = R.mesh; m.dim = dim;
@@ -311,6 +314,23 @@ inline RefinedBox make_refined_box(int dim, const int n[3], const double origin[
     for (auto &mw : hw[i]) { R.cons_u.master.push_back(mw.first * dim + d); R.cons_u.weight.push_back(mw.second); }
     R.cons_u.ptr.push_back((int64_t)R.cons_u.master.size());
   }
+  // the FE functions of the unrefined box evaluated at every displacement node (lattice coordinates are in units h / (2 k_u))
+  {
+    const int k = k_u, n1 = k + 1, ns = ipow(n1, dim); const int64_t nn0 = (int64_t)k * nc[0] + 1, nn1 = (int64_t)k * nc[1] + 1;
+    std::vector<double> val(ns), grad((size_t)ns * dim);
+    R.prol_ptr.assign(1, 0);
+    for (size_t nd = 0; nd < cu.size(); ++nd) {
+      int c[3] = {0, 0, 0}; double xi[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) { c[d] = std::min(cu[nd][d] / (2 * k), nc[d] - 1); xi[d] = (double)(cu[nd][d] - 2 * k * c[d]) / (2 * k); }
+      shape_at(dim, k, xi, val.data(), grad.data());
+      for (int s = 0; s < ns; ++s) if (std::fabs(val[s]) > 1e-13) {
+        const int a[3] = {s % n1, (s / n1) % n1, s / (n1 * n1)};
+        const int64_t node = ((int64_t)(dim == 3 ? k * c[2] + a[2] : 0) * nn1 + (k * c[1] + a[1])) * nn0 + (k * c[0] + a[0]);
+        R.prol_node.push_back((int32_t)node); R.prol_w.push_back(val[s]);
+      }
+      R.prol_ptr.push_back((int64_t)R.prol_node.size());
+    }
+  }
   return R;
 }
 
@@ -341,6 +361,8 @@ struct ProblemData {
   bool ties_added = false;
   bool dirichlet_given = false;       // the Dirichlet list was filled by the caller (pieces of a partition: from the global list)
   std::vector<double> tensor_grid[3]; // vertex planes per direction of a tensor-product grid without the box tag (graded boxes)
+  // locally refined boxes: the underlying uniform box as a problem of its own + the interpolation from it (poro_coarse_space)
+  std::unique_ptr<ProblemData> coarse; std::vector<int64_t> prol_ptr; std::vector<int32_t> prol_node; std::vector<double> prol_w;
   poro_desc d{};
 
   // ConstraintMatrix semantics of PoroElasticDisplacementSolver.h:112-136: hanging-node constraints first, boundary values only for dofs that are
@@ -471,8 +493,14 @@ inline void build_refined_box_problem(ProblemData &P, int dim, const int n[3], c
   for (int d = 0; d < dim; ++d) { h[d] = size[d] / n[d]; origin[d] = -size[d] / 2; }
   RefinedBox R = make_refined_box(dim, n, origin, h, k_u, lo, hi);
   P.mesh = std::move(R.mesh); P.dofs = std::move(R.dofs); P.cons_u = std::move(R.cons_u); P.cons_p = std::move(R.cons_p);
+  P.prol_ptr = std::move(R.prol_ptr); P.prol_node = std::move(R.prol_node); P.prol_w = std::move(R.prol_w);
   P.part = poro_partition{}; P.part.n_ranks = 1;
   P.finalize(k_u, true);
+  // coarse space of the two-level preconditioner: the unrefined box with the same material and boundary conditions
+  P.coarse.reset(new ProblemData()); P.coarse->bc = P.bc; P.coarse->mat = P.mat;
+  build_box_problem(*P.coarse, dim, n, size, k_u);
+  P.d.coarse = poro_coarse_space{}; P.d.coarse.enabled = 1; P.d.coarse.box_problem = &P.coarse->d;
+  P.d.coarse.ptr = P.prol_ptr.data(); P.d.coarse.node = P.prol_node.data(); P.d.coarse.weight = P.prol_w.data();
 }
 
 // ---- general partition (last sentence): contiguous ranges of the cells in Morton order + indexed interface lists --------------

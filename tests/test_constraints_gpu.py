@@ -124,3 +124,45 @@ def test_constraint_lists_are_validated():
             pk.Context(Bad, 0, pk.OP_CSR)
     finally:
         P.close()
+
+
+def test_two_level_preconditioner_on_refined_boxes(trio):
+    """PORO_PREC_TWO_LEVEL: Jacobi on the refined mesh + block fast diagonalisation of the underlying uniform box (poro_desc.coarse, interpolation P) - the same
+    condensed solution as the oracle's Jacobi-CG, in far fewer iterations"""
+    P, O, G = trio
+    assert P.desc.coarse.enabled and G.supports_preconditioner(0, pk.PREC_TWO_LEVEL) and not G.supports_preconditioner(1, pk.PREC_TWO_LEVEL)
+    p = REF["p_init"] * (1 + 0.3 * np.sin(0.37 * np.arange(G.n_p)))
+    for S in (O, G):
+        S.set(pk.VEC_P, p); S.disp_assemble_system(True)
+    rc0, _ = O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=50000)
+    rc1, jac = G.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=50000)
+    G.fill(pk.VEC_U, 0.0)
+    rc2, two = G.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=500, prec=pk.PREC_TWO_LEVEL)
+    assert rc0 == 0 and rc1 == 0 and rc2 == 0 and 0 < two.iterations <= jac.iterations, (two.iterations, jac.iterations)   # (the smallest meshes have a few dozen dofs: both stop at the dimension of the space)
+    assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-9
+
+
+def test_two_level_iteration_counts_do_not_grow_with_refinement():
+    """uniform refinement of the whole configuration (box and refined block): the CG iteration count of the two-level preconditioner grows by less than 1.3x per level,
+    Jacobi's roughly doubles"""
+    from common import BC_3D, material
+    counts, jacobi = [], []
+    for n in (4, 8, 16):
+        P = pk.Problem.refined_box(3, [n] * 3, [10.0] * 3, 2, material(), BC_3D, [n // 4] * 3, [3 * n // 4] * 3)
+        G = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+        try:
+            G.set(pk.VEC_P, REF["p_init"] * (1 + 0.3 * np.sin(0.37 * np.arange(G.n_p)))); G.disp_assemble_system(True)
+            rc, info = G.disp_solve(abs_tol=1e-14, rel_tol=1e-8, max_iter=2000, prec=pk.PREC_TWO_LEVEL)
+            assert rc == 0
+            counts.append(info.iterations)
+            u = G.get(pk.VEC_U)
+            if n <= 8:
+                G.fill(pk.VEC_U, 0.0)
+                rc, info = G.disp_solve(abs_tol=1e-14, rel_tol=1e-8, max_iter=50000)
+                assert rc == 0 and rel2(u, G.get(pk.VEC_U)) <= 1e-6
+                jacobi.append(info.iterations)
+        finally:
+            G.close(); P.close()
+    print("two-level CG iterations per refinement:", counts, "Jacobi:", jacobi)
+    assert counts[1] <= 1.3 * counts[0] and counts[2] <= 1.3 * counts[1], counts
+    assert counts[1] < jacobi[1] / 3, (counts, jacobi)
