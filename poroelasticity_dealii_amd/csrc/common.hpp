@@ -112,7 +112,8 @@ struct FdmOct {
   int own_z = 0;                                  // local node planes that count in dot products (the upper shared plane belongs to the neighbour)
   struct Slab {
     bool on = false; int n_ranks = 1, rank = 0;
-    int ng = 0, hzg = 0;                          // global nodes / half length of a z line
+    int ng = 0, hzg = 0;                          // global nodes of a z line / rows of a transposed block (half length with the parity split, ng without)
+    int np = 2, nb = 12;                          // parity parts of the z direction (2; scalar Q1 systems: 1 = no butterfly), blocks of the local arrays (3 components x 4 quadrants; scalar: 1)
     int cw = 64, nchunk = 0, cps = 0, chunk0 = 0, my_chunks = 0;   // chunk width (columns), chunks per (component, quadrant) plane, chunks per rank share, this rank's first global chunk and count
     int64_t scols = 0;                            // columns of a share = cps cw
     int own = 0, nl = 0, max_own = 0, max_nl = 0, rows_back = 0;    // planes this rank sends (owns) / holds; maxima over the ranks; sum of the ranks' local planes
@@ -369,6 +370,9 @@ bool fdmo_scalar_usable(int dim, const int nn[3]);
 void fdmo_scalar_init(FdmOct &O, const int nn[3], hipStream_t s);
 void fdmo_scalar_upload_dir(FdmOct &O, int dir, const std::vector<double> &S, const std::vector<double> &lam, int n);
 void fdmo_scalar_apply(hipStream_t s, FdmOct &O, double a, double kappa, const double *g, double *z, const PcgScalars *gate = nullptr);
+// slab partitions: nn = LOCAL vertices, the last direction's matrices are uploaded for the GLOBAL line; the three sweeps separately (all-to-alls in between, ctx_prec.hip)
+void fdmo_scalar_init_slab(FdmOct &O, const int nn[3], int rank, const std::vector<int> &node_layers, hipStream_t s);
+void fdmo_scalar_slab_pass(hipStream_t s, FdmOct &O, int pass, double a, double kappa, const double *in, double *out);
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v_nodal, double *q_oct);   // q = H v (node-interleaved vector -> octant form)
 void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r_oct, double *v_nodal);     // v = H^-1-form of the backward transform: v_k = a + b, v_k' = a - b
 // the vector kernels of pcg() with g / z in octant form (same device-side scalar protocol as their nodal counterparts in kernels_la.hip)

@@ -43,8 +43,9 @@ void build_fdm_p(poro_ctx *c) {
   int np3[3] = {c->lines.n[0] + 1, c->lines.n[1] + 1, c->dim == 3 ? c->lines.n[2] + 1 : 1};
   const bool fused = !c->comm.multi() && fdmo_scalar_usable(c->dim, np3) && !std::getenv("PORO_FDM_P_UNFUSED");
   if (fused) fdmo_scalar_init(c->fdm_p_fused, np3, c->stream);
+  bool fused_slab = false;   // decided below, once the global line length is known
   for (int d = 0; d < c->dim; ++d) upload_dir(c->fdm_p.dir[d], c->lines.hcell[d], c->lines.uniform, fused ? &c->fdm_p_fused : nullptr, d);   // local slab; the last direction is replaced below when partitioned
-  c->fdm_p_fused.built = fused;
+  if (!c->comm.multi()) c->fdm_p_fused.built = fused;
   c->fdm_t1.alloc(c->n_p); c->fdm_t2.alloc(c->n_p);
   if (c->comm.multi()) {
     FdmDist &F = c->fdm_dist; const int N = std::max(1, c->comm.part.n_ranks), r = c->comm.part.rank, last = c->dim - 1;
@@ -65,6 +66,15 @@ void build_fdm_p(poro_ctx *c) {
     F.C = (F.ncol_total + N - 1) / N;
     F.max_own = 0; F.max_nl = 0;
     for (int q = 0; q < N; ++q) { F.max_own = std::max(F.max_own, F.layers[q] + (q == N - 1 ? 1 : 0)); F.max_nl = std::max(F.max_nl, F.layers[q] + 1); }
+    // slab form of the same three-launch kernels (kernels_fdmo.hip): 3D, local planes and the global line of at most 80 vertices
+    { int g3[3] = {np3[0], np3[1], acc + 1};
+      fused_slab = c->dim == 3 && fdmo_scalar_usable(3, np3) && fdmo_scalar_usable(3, g3) && !std::getenv("PORO_FDM_P_UNFUSED");
+      if (fused_slab) {
+        fdmo_scalar_init_slab(c->fdm_p_fused, np3, r, F.layers, c->stream);
+        for (int d = 0; d < 2; ++d) { std::vector<double> S, lam; q1_eig(c->box.n[d], c->box.h[d], S, lam); fdmo_scalar_upload_dir(c->fdm_p_fused, d, S, lam, c->box.n[d] + 1); }
+        std::vector<double> S, lam; q1_eig(acc, c->box.h[last], S, lam); fdmo_scalar_upload_dir(c->fdm_p_fused, 2, S, lam, acc + 1);
+        c->fdm_p_fused.built = true;
+      } }
     upload_dir(F.last, std::vector<double>((size_t)acc, c->box.h[last]), true);
     const size_t blk = (size_t)std::max(F.max_own, F.max_nl) * F.C;
     F.sendbuf.alloc(blk * N); F.recvbuf.alloc(blk * N); F.tz1.alloc((size_t)F.ng * F.C); F.tz2.alloc((size_t)F.ng * F.C);
@@ -117,6 +127,17 @@ void fdm_precondition_p(poro_ctx *c, double a, const double k[3], const double *
   if (!c->comm.multi()) {
     if (c->fdm_p_fused.built && k[0] == k[1] && k[1] == k[2]) fdmo_scalar_apply(s, c->fdm_p_fused, a, k[0], g, z);
     else fdm_apply(s, c->fdm_p, a, k, g, z, c->fdm_t1.p, c->fdm_t2.p);
+    return;
+  }
+  if (c->fdm_p_fused.built && c->fdm_p_fused.slab.on && k[0] == k[1] && k[1] == k[2]) {
+    // the slab form of the fused kernels: x / y sweeps on the local planes straight into the exchange buffer, whole z lines per column share, scatter, y / x sweeps
+    FdmOct &O = c->fdm_p_fused; auto &S = O.slab; double *send = S.buf.p, *recv = S.buf.p + S.recv_off;
+    fdmo_scalar_slab_pass(s, O, 1, a, k[0], g, S.buf.p);
+    alltoall_blocks(c, send, recv, (int64_t)S.max_own * S.scols, true);
+    fdmo_scalar_slab_pass(s, O, 2, a, k[0], S.buf.p, S.tz.p);
+    fdmo_slab_scatter_pack(s, O, nullptr);
+    alltoall_blocks(c, send, recv, (int64_t)S.max_nl * S.scols, true);
+    fdmo_scalar_slab_pass(s, O, 3, a, k[0], S.buf.p, z);
     return;
   }
   FdmDist &F = c->fdm_dist; const FdmScalar &L = c->fdm_p;

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_dot_owned(OctDims D, const doub
 
 // ---- slab form: the z transform needs whole global lines.  Columns = (component, quadrant, plane position), grouped in chunks of cw; rank q transforms chunks
 //      [q cps, (q + 1) cps).  Two all-to-alls of [rank][plane][share column] buffers; the z butterfly rides in the unpack / pack next to the transposed array ----
-struct SlabGeo { int cw, nchunk, cps, chunk_total, rank, my_chunks, hzg, ng; int64_t scols, pl, co; };
+struct SlabGeo { int cw, nchunk, cps, chunk_total, rank, my_chunks, hzg, ng, np; int64_t scols, pl, co; };
 // transposed array -> send buffer: every rank's planes (shared ones to both owners), v_k = a + b, v_k' = a - b
 __global__ void __launch_bounds__(256) k_fdmo_slab_scatter_pack(SlabGeo S, int rows, const int64_t *__restrict__ row_out, const int32_t *__restrict__ row_kz,
                                                                   const double *__restrict__ tz, double *__restrict__ buf, const PcgScalars *gate) {
@@ -222,7 +222,9 @@ __global__ void __launch_bounds__(256) k_fdmo_slab_scatter_pack(SlabGeo S, int r
   const int per_row = S.my_chunks * S.cw, total = rows * per_row;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     const int row = e / per_row, col = e - row * per_row, cl = col / S.cw, j = col - cl * S.cw;
-    const int kz = row_kz[row], mz = S.ng - 1 - kz, kh = min(kz, mz);
+    const int kz = row_kz[row];
+    if (S.np == 1) { buf[row_out[row] + col] = tz[((int64_t)cl * S.hzg + kz) * S.cw + j]; continue; }     // (scalar systems: no parity split)
+    const int mz = S.ng - 1 - kz, kh = min(kz, mz);
     const double a = tz[((int64_t)(2 * cl) * S.hzg + kh) * S.cw + j], b = tz[((int64_t)(2 * cl + 1) * S.hzg + kh) * S.cw + j];
     buf[row_out[row] + col] = kz == mz ? a : (kz < mz ? a + b : a - b);
   }
@@ -241,7 +243,7 @@ struct OctPass {
   const double *T1[3][2], *T2[3][2];                     // [component][parity], MFMA fragment order [tile][4 NT][64]
   const double *lam_z[3][2]; double cz[3]; const double *bxy;   // mode 1: eigenvalues of the line direction; bxy[(4 c + (o & 3)) pl + column] = the other two directions' share
   int no_shift;                 // log2 of the blocks per component (3: octants, 2: quadrants of the slab form, 0: scalar system)
-  int slab_z, chunk0, chunk_total, nchunk;   // slab form, pass 2: workgroup = (local chunk, z parity) of the transposed array; its global chunk number gives (component, quadrant, chunk of the plane)
+  int slab_z /* parity parts of the transposed blocks: 2, or 1 for the scalar systems; 0: not the slab form */, chunk0, chunk_total, nchunk;   // slab form, pass 2: workgroup = (local chunk, z parity) of the transposed array; its global chunk number gives (component, quadrant, chunk of the plane)
   // slab form: the copies around the all-to-alls ride in the passes.  The exchange buffer is [send | recv], each [rank q][plane][share column]; column X = (block) nchunk cw +
   // plane position belongs to rank q = X / scols, so its address is X + q (pitch - 1) scols + plane scols: pass 1 (slab_io = 1) stores there (planes >= store_planes are the
   // neighbour's and are not sent; the own share goes straight to the receive half), pass 3 (slab_io = 2) loads the scattered planes from there; pass 2 (row_in): offset of every
@@ -287,9 +289,9 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   const int j = lane & 15, kq = lane >> 4;
   int b, c, o, co = 0; int64_t base;
   if (MODE == 1 && P.slab_z) {
-    const int G = P.chunk0 + (int)(blockIdx.x >> 1), cq = G / P.nchunk;
+    const int G = P.chunk0 + (int)(blockIdx.x >> (P.slab_z - 1)), cq = G / P.nchunk;
     if (G >= P.chunk_total) return;                                  // (the last rank's share may be short; workgroup-uniform, before any barrier)
-    b = G - cq * P.nchunk; c = cq >> 2; o = (cq & 3) | ((blockIdx.x & 1) << 2); base = (int64_t)blockIdx.x * P.blk_stride;
+    b = G - cq * P.nchunk; c = cq >> 2; o = (cq & 3) | ((blockIdx.x & (P.slab_z - 1)) << 2); base = (int64_t)blockIdx.x * P.blk_stride;
   } else {
     co = blockIdx.x / P.nblk;
     b = blockIdx.x % P.nblk; c = co >> P.no_shift; o = co & ((1 << P.no_shift) - 1); base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
@@ -321,11 +323,14 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
     for (int u = 0; u < PER; ++u) {
       const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP);
       if (MODE == 1 && P.row_in) {             // gathered planes -> parity part of the global line: e_k = v_k + v_k', o_k = v_k - v_k' (centre plane: e = v, o = 0)
-        const bool ok = e < TOT && r < R && c2 < C; const int rr = ok ? r : 0, mr = P.ng - 1 - rr; const int64_t cb = (int64_t)(blockIdx.x >> 1) * P.C + c2;
+        const bool ok = e < TOT && r < R && c2 < C, split = P.slab_z == 2; const int rr = ok ? r : 0, mr = split ? P.ng - 1 - rr : rr; const int64_t cb = (int64_t)(blockIdx.x >> (P.slab_z - 1)) * P.C + c2;
         const double2 lo = ok ? *reinterpret_cast<const double2 *>(in + P.row_in[rr] + cb) : double2{0.0, 0.0}, hi = (ok && mr != rr) ? *reinterpret_cast<const double2 *>(in + P.row_in[mr] + cb) : double2{0.0, 0.0};
-        const bool odd = blockIdx.x & 1;
+        const bool odd = split && (blockIdx.x & 1);
         stage[u].x = odd ? (mr != rr ? lo.x - hi.x : 0.0) : lo.x + hi.x; stage[u].y = odd ? (mr != rr ? lo.y - hi.y : 0.0) : lo.y + hi.y;
-      } else if (MODE == 2 && P.slab_io == 2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + slab_at(r * (int)P.row_stride + c2)) : double2{0.0, 0.0};
+      } else if (MODE == 2 && P.slab_io == 2) {
+        if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + slab_at(r * (int)P.row_stride + c2)) : double2{0.0, 0.0};
+        else { stage[u].x = (e < TOT && r < R && c2 < C) ? in[slab_at(r * (int)P.row_stride + c2)] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? in[slab_at(r * (int)P.row_stride + c2 + 1)] : 0.0; }
+      }
       else if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
       else { const double *src = in + base + (int64_t)r * P.row_stride + c2; stage[u].x = (e < TOT && r < R && c2 < C) ? src[0] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? src[1] : 0.0; }
     }
@@ -468,7 +473,7 @@ void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const
 }
 inline int oct_grid(int64_t co) { return (int)std::min<int64_t>((3 * co + kBlock - 1) / kBlock, kMaxPartials); }   // threads = positions x components, as many per thread as the partial slots demand
 OctDims dims_of(const FdmOct &O) { return OctDims{O.n[0], O.n[1], O.n[2], O.h[0], O.h[1], O.h[2], O.hxp, O.co_stride, O.no, O.own_z}; }
-SlabGeo geo_of(const FdmOct &O) { const auto &S = O.slab; return SlabGeo{S.cw, S.nchunk, S.cps, 3 * O.no * S.nchunk, S.rank, S.my_chunks, S.hzg, S.ng, S.scols, (int64_t)O.hxp * O.h[1], O.co_stride}; }
+SlabGeo geo_of(const FdmOct &O) { const auto &S = O.slab; return SlabGeo{S.cw, S.nchunk, S.cps, S.nb * S.nchunk, S.rank, S.my_chunks, S.hzg, S.ng, S.np, S.scols, (int64_t)O.hxp * O.h[1], O.co_stride}; }
 
 }  // namespace
 
@@ -487,35 +492,52 @@ void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t 
   O.g.alloc(O.n_oct); O.z.alloc(O.n_oct); O.t.alloc(O.n_oct);
   O.g.zero(s); O.z.zero(s); O.t.zero(s);
 }
-void fdmo_init_slab(FdmOct &O, const int nn[3], const double coef[3][3], int rank, const std::vector<int> &node_layers, bool has_upper, hipStream_t s) {
+// chunks, shares, plane tables and buffers of the slab form, after n / h / hxp / nt / co_stride are set: nb blocks per plane position set, np parity parts of a z line
+static void slab_layout(FdmOct &O, int nb, int np, int rank, const std::vector<int> &node_layers, hipStream_t s) {
   auto &S = O.slab; const int N = (int)node_layers.size();
-  S.on = true; S.n_ranks = N; S.rank = rank;
-  S.ng = 1; for (int q = 0; q < N; ++q) S.ng += node_layers[q];
-  S.hzg = (S.ng + 1) / 2;
-  if (nn[2] != node_layers[rank] + 1) throw Error("fdmo_init_slab: local planes do not match the layer table");
-  int hmax = S.hzg;
-  for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = d < 2 ? (nn[d] + 1) / 2 : nn[d]; if (d < 2) hmax = std::max(hmax, O.h[d]); for (int c = 0; c < 3; ++c) O.coef[c][d] = coef[c][d]; }
-  O.nt = (hmax + 15) / 16;
-  O.hxp = (O.h[0] + 1) & ~1; O.no = 4; O.own_z = has_upper ? nn[2] - 1 : nn[2];
-  O.co_stride = (int64_t)O.hxp * O.h[1] * O.h[2]; O.n_oct = 12 * O.co_stride;
-  O.g.alloc(O.n_oct); O.z.alloc(O.n_oct); O.t.alloc(O.n_oct);
-  O.g.zero(s); O.z.zero(s); O.t.zero(s);
+  S.nb = nb; S.np = np; S.hzg = np == 2 ? (S.ng + 1) / 2 : S.ng;
   const int64_t pl = (int64_t)O.hxp * O.h[1];
   S.cw = 16 * std::min(O.nt, 4); S.nchunk = (int)((pl + S.cw - 1) / S.cw);
-  const int chunk_total = 12 * S.nchunk;
+  const int chunk_total = nb * S.nchunk;
   S.cps = (chunk_total + N - 1) / N; S.chunk0 = rank * S.cps; S.my_chunks = std::max(0, std::min(S.cps, chunk_total - S.chunk0)); S.scols = (int64_t)S.cps * S.cw;
   std::vector<int> off(N), own(N), nl(N); int acc = 0; S.max_own = S.max_nl = S.rows_back = 0;
   for (int q = 0; q < N; ++q) { off[q] = acc; acc += node_layers[q]; own[q] = node_layers[q] + (q == N - 1 ? 1 : 0); nl[q] = node_layers[q] + 1; S.max_own = std::max(S.max_own, own[q]); S.max_nl = std::max(S.max_nl, nl[q]); S.rows_back += nl[q]; }
   S.own = own[rank]; S.nl = nl[rank];
-  if ((int64_t)std::max(S.max_own, S.max_nl) * chunk_total * S.cw >= (int64_t)1 << 31 || (int64_t)S.rows_back * S.scols >= (int64_t)1 << 31) throw Error("fdmo_init_slab: a slab of more than 2^31 transform entries");
+  if ((int64_t)std::max(S.max_own, S.max_nl) * chunk_total * S.cw >= (int64_t)1 << 31 || (int64_t)S.rows_back * S.scols >= (int64_t)1 << 31 || (int64_t)chunk_total * S.cw >= (int64_t)1 << 24) throw Error("fdmo: a slab of more than 2^31 transform entries");
   // one buffer [send | recv]; what a rank keeps for itself is written straight into the receive half
   const int64_t blk = (int64_t)std::max(S.max_own, S.max_nl) * S.scols; S.recv_off = blk * N;
   std::vector<int64_t> rin(S.ng), rout(S.rows_back); std::vector<int32_t> rkz(S.rows_back);
   for (int q = 0; q < N; ++q) for (int k = 0; k < own[q]; ++k) rin[off[q] + k] = S.recv_off + ((int64_t)q * S.max_own + k) * S.scols;
   { int r = 0; for (int q = 0; q < N; ++q) for (int k = 0; k < nl[q]; ++k, ++r) { rout[r] = ((int64_t)q * S.max_nl + k) * S.scols + (q == rank ? S.recv_off : 0); rkz[r] = off[q] + k; } }
   S.row_in.upload(rin); S.row_out.upload(rout); S.row_kz.upload(rkz);
-  S.buf.alloc((size_t)2 * blk * N); S.tz.alloc((size_t)2 * S.cps * S.hzg * S.cw);
+  S.buf.alloc((size_t)2 * blk * N); S.tz.alloc((size_t)np * S.cps * S.hzg * S.cw);
   S.buf.zero(s); S.tz.zero(s);
+}
+void fdmo_init_slab(FdmOct &O, const int nn[3], const double coef[3][3], int rank, const std::vector<int> &node_layers, bool has_upper, hipStream_t s) {
+  auto &S = O.slab; const int N = (int)node_layers.size();
+  S.on = true; S.n_ranks = N; S.rank = rank;
+  S.ng = 1; for (int q = 0; q < N; ++q) S.ng += node_layers[q];
+  if (nn[2] != node_layers[rank] + 1) throw Error("fdmo_init_slab: local planes do not match the layer table");
+  int hmax = (S.ng + 1) / 2;
+  for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = d < 2 ? (nn[d] + 1) / 2 : nn[d]; if (d < 2) hmax = std::max(hmax, O.h[d]); for (int c = 0; c < 3; ++c) O.coef[c][d] = coef[c][d]; }
+  O.nt = (hmax + 15) / 16;
+  O.hxp = (O.h[0] + 1) & ~1; O.no = 4; O.own_z = has_upper ? nn[2] - 1 : nn[2];
+  O.co_stride = (int64_t)O.hxp * O.h[1] * O.h[2]; O.n_oct = 12 * O.co_stride;
+  O.g.alloc(O.n_oct); O.z.alloc(O.n_oct); O.t.alloc(O.n_oct);
+  O.g.zero(s); O.z.zero(s); O.t.zero(s);
+  slab_layout(O, 12, 2, rank, node_layers, s);
+}
+// scalar Q1 system on a slab: nodal layout [local plane][y][x], whole-length lines everywhere (no parity split)
+void fdmo_scalar_init_slab(FdmOct &O, const int nn[3], int rank, const std::vector<int> &node_layers, hipStream_t s) {
+  auto &S = O.slab; const int N = (int)node_layers.size();
+  S.on = true; S.n_ranks = N; S.rank = rank;
+  S.ng = 1; for (int q = 0; q < N; ++q) S.ng += node_layers[q];
+  if (nn[2] != node_layers[rank] + 1) throw Error("fdmo_scalar_init_slab: local planes do not match the layer table");
+  int hmax = S.ng;
+  for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = nn[d]; if (d < 2) hmax = std::max(hmax, nn[d]); }
+  O.nt = (hmax + 15) / 16; O.hxp = nn[0]; O.no = 1;
+  O.co_stride = (int64_t)nn[0] * nn[1] * nn[2]; O.n_oct = O.co_stride;
+  slab_layout(O, 1, 1, rank, node_layers, s);
 }
 
 bool fdmo_upload_dir(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn) {
@@ -606,7 +628,7 @@ void fdmo_slab_pass(hipStream_t s, const FdmOct &O, int pass, const double *in, 
   for (int c = 0; c < 3; ++c) { P.cz[c] = O.coef[c][2]; for (int p = 0; p < 2; ++p) P.lam_z[c][p] = O.lam[c][2][p].p; }
   if (pass == 2) {
     P.mode = 1; P.R = S.hzg; P.C = S.cw; P.nt_r = tiles(S.hzg); P.nt_c = S.cw / 16; P.kk1 = P.kk2 = ksteps(S.hzg); P.nblk = 1; P.blk_stride = (int64_t)S.hzg * S.cw; P.row_stride = S.cw; P.bit1 = P.bit2 = 2;
-    P.slab_z = 1; P.chunk0 = S.chunk0; P.chunk_total = 12 * S.nchunk; P.nchunk = S.nchunk; P.row_in = S.row_in.p; P.ng = S.ng;
+    P.slab_z = 2; P.chunk0 = S.chunk0; P.chunk_total = 12 * S.nchunk; P.nchunk = S.nchunk; P.row_in = S.row_in.p; P.ng = S.ng;
     for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][2][p].p; P.T2[c][p] = O.bwd[c][2][p].p; }
     if (S.my_chunks > 0) launch_pass_nt(s, nt, P, 2 * S.my_chunks, in, out, e0, e1);
     return;
@@ -639,6 +661,7 @@ void fdmo_scalar_init(FdmOct &O, const int nn[3], hipStream_t s) {
   O.t.alloc(O.n_oct); O.t.zero(s);
 }
 void fdmo_scalar_upload_dir(FdmOct &O, int dir, const std::vector<double> &S, const std::vector<double> &lam, int n) {   // S: n x n row-major, columns = M-orthonormal eigenvectors
+  if (n != (O.slab.on && dir == 2 ? O.slab.ng : O.n[dir])) throw Error("fdmo_scalar_upload_dir: line length mismatch");
   const int nt = O.nt, kkp = 4 * nt, padn = 16 * nt;
   std::vector<double> F((size_t)nt * kkp * 64, 0.0), B((size_t)nt * kkp * 64, 0.0), lp(padn + 16, std::numeric_limits<double>::infinity());
   for (int t = 0; t < nt; ++t) for (int kk = 0; kk < kkp; ++kk) for (int l = 0; l < 64; ++l) {
@@ -648,17 +671,11 @@ void fdmo_scalar_upload_dir(FdmOct &O, int dir, const std::vector<double> &S, co
   for (int m = 0; m < n; ++m) lp[m] = lam[m];
   O.h_lam[0][dir][0] = lp; O.fwd[0][dir][0].upload(F); O.bwd[0][dir][0].upload(B); O.lam[0][dir][0].upload(lp);
 }
+static const double *scalar_table(hipStream_t s, FdmOct &O, double a, double kappa);
 // z = (a M + kappa K)^-1 g; the x / y share a + kappa (lam_x + lam_y) of the eigenvalue sums is tabulated per plane position, one table per (a, kappa)
 void fdmo_scalar_apply(hipStream_t s, FdmOct &O, double a, double kappa, const double *g, double *z, const PcgScalars *gate) {
   const int nt = O.nt, hx = O.h[0], hy = O.h[1], hz = O.h[2];
-  const double *table = nullptr;
-  for (auto &T : O.scalar_tables) if (T.a == a && T.kappa == kappa) table = T.t.p;
-  if (!table) {
-    if (O.scalar_tables.size() >= 8) { PORO_HIP(hipStreamSynchronize(s)); O.scalar_tables.pop_front(); }   // (a changing coefficient, e.g. a varying time step: drop the oldest)
-    std::vector<double> Bt((size_t)hx * hy);
-    for (int my = 0; my < hy; ++my) for (int mx = 0; mx < hx; ++mx) Bt[(size_t)my * hx + mx] = a + kappa * (O.h_lam[0][0][0][mx] + O.h_lam[0][1][0][my]);
-    O.scalar_tables.emplace_back(); auto &T = O.scalar_tables.back(); T.a = a; T.kappa = kappa; T.t.upload(Bt); table = T.t.p;
-  }
+  const double *table = scalar_table(s, O, a, kappa);
   auto tiles = [](int n) { return (n + 15) / 16; };
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
@@ -674,6 +691,37 @@ void fdmo_scalar_apply(hipStream_t s, FdmOct &O, double a, double kappa, const d
   P.mode = 2; P.R = hy; P.C = hx; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hy); P.kk2 = ksteps(hx); P.nblk = hz; P.blk_stride = (int64_t)hx * hy; P.row_stride = hx; P.bit1 = 1; P.bit2 = 0;
   P.T1[0][0] = O.bwd[0][1][0].p; P.T2[0][0] = O.bwd[0][0][0].p;
   launch_pass_nt(s, nt, P, P.nblk, O.t.p, z);
+}
+
+static const double *scalar_table(hipStream_t s, FdmOct &O, double a, double kappa) {
+  for (auto &T : O.scalar_tables) if (T.a == a && T.kappa == kappa) return T.t.p;
+  const int hx = O.h[0], hy = O.h[1];
+  if (O.scalar_tables.size() >= 8) { PORO_HIP(hipStreamSynchronize(s)); O.scalar_tables.pop_front(); }   // (a changing coefficient, e.g. a varying time step: drop the oldest)
+  std::vector<double> Bt((size_t)hx * hy);
+  for (int my = 0; my < hy; ++my) for (int mx = 0; mx < hx; ++mx) Bt[(size_t)my * hx + mx] = a + kappa * (O.h_lam[0][0][0][mx] + O.h_lam[0][1][0][my]);
+  O.scalar_tables.emplace_back(); auto &T = O.scalar_tables.back(); T.a = a; T.kappa = kappa; T.t.upload(Bt); return T.t.p;
+}
+void fdmo_scalar_slab_pass(hipStream_t s, FdmOct &O, int pass, double a, double kappa, const double *in, double *out) {
+  const auto &S = O.slab; const int nt = O.nt, hx = O.h[0], hy = O.h[1], nzl = O.h[2];
+  auto tiles = [](int n) { return (n + 15) / 16; };
+  auto ksteps = [](int n) { return (n + 3) / 4; };
+  OctPass P{};
+  P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = scalar_table(s, O, a, kappa); P.vec2 = 0; P.no_shift = 0;
+  P.cz[0] = kappa; P.lam_z[0][0] = O.lam[0][2][0].p;
+  if (pass == 2) {
+    P.mode = 1; P.R = S.ng; P.C = S.cw; P.nt_r = tiles(S.ng); P.nt_c = S.cw / 16; P.kk1 = P.kk2 = ksteps(S.ng); P.nblk = 1; P.blk_stride = (int64_t)S.hzg * S.cw; P.row_stride = S.cw; P.bit1 = P.bit2 = 2;
+    P.slab_z = 1; P.chunk0 = S.chunk0; P.chunk_total = S.nchunk; P.nchunk = S.nchunk; P.row_in = S.row_in.p; P.ng = S.ng; P.vec2 = 1;
+    P.T1[0][0] = O.fwd[0][2][0].p; P.T2[0][0] = O.bwd[0][2][0].p;
+    if (S.my_chunks > 0) launch_pass_nt(s, nt, P, S.my_chunks, in, out);
+    return;
+  }
+  const bool first = pass == 1;
+  P.mode = first ? 0 : 2; P.R = hy; P.C = hx; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(first ? hx : hy); P.kk2 = ksteps(first ? hy : hx); P.nblk = nzl; P.blk_stride = (int64_t)hx * hy; P.row_stride = hx;
+  P.bit1 = first ? 0 : 1; P.bit2 = first ? 1 : 0;
+  P.T1[0][0] = first ? O.fwd[0][0][0].p : O.bwd[0][1][0].p; P.T2[0][0] = first ? O.fwd[0][1][0].p : O.bwd[0][0][0].p;
+  P.slab_io = first ? 1 : 2; P.store_planes = S.own; P.scols = (int)S.scols; P.inv_scols = 1.0f / (float)S.scols; P.col_unit = S.nchunk * S.cw; P.rank = S.rank;
+  P.dest_stride = (int64_t)((first ? S.max_own : S.max_nl) - 1) * S.scols; P.recv_off = S.recv_off;
+  launch_pass_nt(s, nt, P, P.nblk, in, out);
 }
 
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v, double *q) { hipLaunchKernelGGL(k_fdmo_from_nodal, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), v, (const uint8_t *)nullptr, q); }
