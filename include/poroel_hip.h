@@ -308,6 +308,9 @@ int  poro_proj_assemble_matrix(poro_ctx *ctx);
 int  poro_proj_assemble_rhs(poro_ctx *ctx, const int32_t *tensor_components, int32_t n_comp);
 /* StrainProjector<dim>::solve_projection_system (:201-232); rhs_entry = packed symmetric entry */
 int  poro_proj_solve(poro_ctx *ctx, int32_t rhs_entry, const poro_solver_opts *opts, poro_solve_info *info);
+/* the loop of StrainProjector::solve_projection_system over several entries (PoroelasticityFSS.h:157-163) in one call: where PORO_PREC_FDM is the exact inverse of the
+ * projection mass matrix the systems are solved directly and together (info[e].iterations = 0, residual checked against the stopping rule), otherwise entry by entry */
+int  poro_proj_solve_many(poro_ctx *ctx, const int32_t *rhs_entries, int32_t n_entries, const poro_solver_opts *opts, poro_solve_info *info /* [n_entries] */);
 /* PoroElasticProblem<dim>::get_volumetric_strain (PoroelasticityFSS.h:179-186): eps_v = sum of normal strains */
 int  poro_get_volumetric_strain(poro_ctx *ctx);
 /* PoroElasticProblem<dim>::get_effective_stresses (PoroelasticityFSS.h:189-224): sigma' = C : eps at every pressure node, C = isotropic_gassman_tensor

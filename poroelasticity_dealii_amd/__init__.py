@@ -100,7 +100,7 @@ HIP_SYMBOLS = [
     "poro_last_error", "poro_abi_version", "poro_ctx_create", "poro_ctx_destroy", "poro_ctx_synchronize", "poro_comm_unique_id", "poro_ctx_comm_init_rccl",
     "poro_ctx_comm_init_callbacks", "poro_vec_set", "poro_vec_get", "poro_vec_fill", "poro_vec_copy", "poro_vec_axpy", "poro_vec_norm",
     "poro_state_save", "poro_state_restore", "poro_disp_assemble_system", "poro_disp_solve", "poro_supports_preconditioner", "poro_pres_assemble_residual", "poro_pres_apply_boundary_values", "poro_pres_assemble_jacobian", "poro_pres_solve",
-    "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_get_volumetric_strain", "poro_get_effective_stresses",
+    "poro_pres_update_volumetric_strain", "poro_proj_assemble_matrix", "poro_proj_assemble_rhs", "poro_proj_solve", "poro_proj_solve_many", "poro_get_volumetric_strain", "poro_get_effective_stresses",
     "poro_export_csr_size", "poro_export_csr", "poro_apply_operator", "poro_apply_preconditioner_u", "poro_bench_operator", "poro_timers_reset", "poro_timers_enable", "poro_timers_get"]
 
 _hip = None
@@ -145,6 +145,7 @@ def load_hip():
         L.poro_proj_assemble_matrix.argtypes = [C.c_void_p]
         L.poro_proj_assemble_rhs.argtypes = [C.c_void_p, _ip, C.c_int32]
         L.poro_proj_solve.argtypes = [C.c_void_p, C.c_int32, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]
+        L.poro_proj_solve_many.argtypes = [C.c_void_p, _ip, C.c_int32, C.POINTER(SolverOpts), C.POINTER(SolveInfo)]
         L.poro_get_volumetric_strain.argtypes = [C.c_void_p]
         L.poro_get_effective_stresses.argtypes = [C.c_void_p]
         L.poro_export_csr_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -424,6 +425,12 @@ class Context:
         info = SolveInfo()
         rc = self._chk(self.L.poro_proj_solve(self.ptr, entry, C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega)), C.byref(info)))
         return rc, info
+
+    def proj_solve_many(self, entries, abs_tol=0.0, rel_tol=1e-8, max_iter=1000, prec=PREC_JACOBI, omega=1.0):
+        """several projection systems in one call (solved directly and together where PREC_FDM is the exact inverse: info.iterations == 0)"""
+        ent, pe = _arr_i(list(entries)); infos = (SolveInfo * len(entries))()
+        rc = self._chk(self.L.poro_proj_solve_many(self.ptr, pe, len(entries), C.byref(self._opts(abs_tol, rel_tol, max_iter, prec, omega)), infos))
+        return rc, list(infos)
 
     def get_volumetric_strain(self):
         self._chk(self.L.poro_get_volumetric_strain(self.ptr))

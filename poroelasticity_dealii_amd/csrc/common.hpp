@@ -205,7 +205,7 @@ struct poro_ctx {
   poro::DevBuf<double> lift_u, neumann_u, diag_u, diag_u_local, diag_J, diag_M, src_local;
   poro::DevBuf<double> dinv_u, dinv_J, dinv_M;   // reciprocals of the Jacobi diagonals
   poro::DevBuf<uint8_t> diag_u_cls; poro::DevBuf<double> diag_u_tab;   // dictionary form of diag_u (uniform boxes): class per node + table[class][dim]
-  poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p;
+  poro::DevBuf<double> wg_u, wd_u, wh_u, wg_p, wd_p, wh_p, tmp_p, proj_y;
   bool box_asm_checked = false;
   int box_asm = 0 /* 0 off, 1 unchecked, 2 checked against the per-cell kernels */; poro::BoxCoupling box_cpl{};
   poro::DevBuf<double> ilu_u, ilu_J, ilu_M; bool ilu_u_valid = false, ilu_J_valid = false, ilu_M_valid = false;   // ILU(0) factors on the CSR patterns
@@ -370,6 +370,9 @@ bool fdmo_scalar_usable(int dim, const int nn[3]);
 void fdmo_scalar_init(FdmOct &O, const int nn[3], hipStream_t s);
 void fdmo_scalar_upload_dir(FdmOct &O, int dir, const std::vector<double> &S, const std::vector<double> &lam, int n);
 void fdmo_scalar_apply(hipStream_t s, FdmOct &O, double a, double kappa, const double *g, double *z, const PcgScalars *gate = nullptr);
+void fdmo_scalar_apply_many(hipStream_t s, FdmOct &O, double a, double kappa, int nb, const double *const *g, double *const *z, const PcgScalars *gate = nullptr);   // up to 3 right-hand sides in one set of launches
+// block partials of |y_e - b_e|^2 and |b_e|^2 for up to three (y, b) pairs: sets 2e and 2e + 1 of `partials`
+void la_residual_norms_many(hipStream_t s, int nb, const double *const *y, const double *const *b, int64_t n, double *partials);
 // slab partitions: nn = LOCAL vertices, the last direction's matrices are uploaded for the GLOBAL line; the three sweeps separately (all-to-alls in between, ctx_prec.hip)
 void fdmo_scalar_init_slab(FdmOct &O, const int nn[3], int rank, const std::vector<int> &node_layers, hipStream_t s);
 void fdmo_scalar_slab_pass(hipStream_t s, FdmOct &O, int pass, double a, double kappa, const double *in, double *out);

@@ -636,6 +636,49 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
   });
 }
 
+// Several projection systems at once (the three normal strains of a time step, PoroelasticityFSS.h:153-164).  Where the fast diagonalisation is the EXACT inverse of the
+// projection mass matrix (uniform box or tensor grid, one rank, no constraint lists) the systems are solved directly: x_e = M^-1 b_e for all of them in one set of three
+// launches, then ||M x_e - b_e|| is checked against the stopping rule of the reference's CG (SolverControl, StrainProjector.h:209) and one poll returns all norms.
+// Otherwise - or if a check fails - every entry goes through poro_proj_solve.  info[e].iterations = 0 marks a directly solved entry.
+int poro_proj_solve_many(poro_ctx *c, const int32_t *entries, int32_t n_entries, const poro_solver_opts *opts, poro_solve_info *info) {
+  if (!c || !entries || !opts || n_entries < 0) { g_err = "null argument"; return -1; }
+  int done_direct = 0;
+  const int rc0 = guarded([&] {
+    PORO_HIP(hipSetDevice(c->device));
+    if (!c->projection_matrix_ready) throw Error("proj_solve before proj_assemble_matrix");
+    for (int e = 0; e < n_entries; ++e) if (entries[e] < 0 || entries[e] >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
+    static const bool iterative = std::getenv("PORO_PROJ_ITERATIVE") != nullptr;
+    const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;
+    if (iterative || opts->preconditioner != PORO_PREC_FDM || opts->stop_rule != PORO_STOP_RHS || c->comm.multi() || c->cons_p.n || !stencil || n_entries < 1 || n_entries > 3 || !fdm_p_supported(c)) return 0;
+    build_fdm_p(c);
+    if (!c->fdm_p_fused.built || c->fdm_p_fused.slab.on) return 0;
+    hipStream_t s = c->stream; const double *b[3]; double *x[3]; const double *y[3];
+    if (c->proj_y.n < (size_t)3 * c->n_p) c->proj_y.alloc((size_t)3 * c->n_p);
+    for (int e = 0; e < n_entries; ++e) { b[e] = vec(c, PORO_VEC_PROJ_RHS0 + entries[e]); x[e] = vec(c, PORO_VEC_STRAIN0 + entries[e]); y[e] = c->proj_y.p + (size_t)e * c->n_p; }
+    const auto t0 = std::chrono::steady_clock::now();
+    { Timed tm(c, "precondition_p_fdm"); fdmo_scalar_apply_many(s, c->fdm_p_fused, 1.0, 0.0, n_entries, b, x); }
+    for (int e = 0; e < n_entries; ++e) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(s, c->dim, c->box, 1.0, 0.0, x[e], const_cast<double *>(y[e])); }
+    la_residual_norms_many(s, n_entries, y, b, c->n_p, c->partials.p);
+    pcg_scalars_sum(s, c->partials.p, 2 * n_entries, c->red.p);
+    post_and_wait(c, c->red.p, 2 * n_entries);
+    bool all = true;
+    for (int e = 0; e < n_entries; ++e) {
+      const double res = std::sqrt(c->mailbox->vals[2 * e]), bn = std::sqrt(c->mailbox->vals[2 * e + 1]);
+      const bool ok = res <= std::max(opts->abs_tol, opts->rel_tol * bn);
+      all = all && ok;
+      if (info) { info[e] = poro_solve_info{}; info[e].iterations = 0; info[e].converged = ok ? 1 : 0; info[e].initial_residual = bn; info[e].final_residual = res; info[e].operator_applications = 1;
+                  info[e].seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / n_entries; }
+    }
+    done_direct = all ? 1 : 0;     // (a failed check leaves x_e = M^-1 b_e as the warm start of the iterative solve below)
+    return 0;
+  });
+  if (rc0 != 0) return rc0;
+  if (done_direct) return 0;
+  int worst = 0;
+  for (int e = 0; e < n_entries; ++e) { const int rc = poro_proj_solve(c, entries[e], opts, info ? info + e : nullptr); if (rc < 0) return rc; worst = std::max(worst, rc); }
+  return worst;
+}
+
 int poro_get_volumetric_strain(poro_ctx *c) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));

@@ -242,7 +242,7 @@ void setup(poro_ctx *c, const poro_desc *d) {
                                      c->vec[PORO_VEC_STRESS0 + e].alloc(c->n_p); c->vec[PORO_VEC_STRESS0 + e].zero(s); }
   for (DevBuf<double> *b : {&c->lift_u, &c->neumann_u, &c->diag_u_local, &c->wg_u, &c->wd_u, &c->wh_u}) { b->alloc(c->n_u); b->zero(s); }
   for (DevBuf<double> *b : {&c->diag_J, &c->diag_M, &c->src_local, &c->wg_p, &c->wd_p, &c->wh_p, &c->tmp_p}) { b->alloc(c->n_p); b->zero(s); }
-  c->partials.alloc((size_t)4 * kMaxPartials); c->partials.zero(s); c->scal.alloc(1); c->scal.zero(s); c->red.alloc(kScalarSlots); c->red.zero(s);
+  c->partials.alloc((size_t)6 * kMaxPartials); c->partials.zero(s); c->scal.alloc(1); c->scal.zero(s); c->red.alloc(kScalarSlots); c->red.zero(s);
 
   // MatrixCreator::create_mass_matrix / create_laplace_matrix (:96-101) + the time-independent well integral (:142-147)
   c->Mp.zero(s); c->Kp.zero(s); c->Jp.zero(s);

@@ -242,6 +242,8 @@ struct OctPass {
   int hx, pl;               // mode 1: columns of a plane = hx hy; a column's plane offset -> (my, mx)
   const double *T1[3][2], *T2[3][2];                     // [component][parity], MFMA fragment order [tile][4 NT][64]
   const double *lam_z[3][2]; double cz[3]; const double *bxy;   // mode 1: eigenvalues of the line direction; bxy[(4 c + (o & 3)) pl + column] = the other two directions' share
+  int64_t in_off[3], out_off[3]; int use_in_off, use_out_off;   // batched scalar systems (no_shift = 0, up to 3 blocks = right-hand sides in separate vectors): element offsets of every block from `in` / `out`
+  int bxy_cmul;                 // bxy table: blocks per component (4: displacement system; 0: the scalar systems share one table)
   int no_shift;                 // log2 of the blocks per component (3: octants, 2: quadrants of the slab form, 0: scalar system)
   int slab_z /* parity parts of the transposed blocks: 2, or 1 for the scalar systems; 0: not the slab form */, chunk0, chunk_total, nchunk;   // slab form, pass 2: workgroup = (local chunk, z parity) of the transposed array; its global chunk number gives (component, quadrant, chunk of the plane)
   // slab form: the copies around the all-to-alls ride in the passes.  The exchange buffer is [send | recv], each [rank q][plane][share column]; column X = (block) nchunk cw +
@@ -296,6 +298,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
     co = blockIdx.x / P.nblk;
     b = blockIdx.x % P.nblk; c = co >> P.no_shift; o = co & ((1 << P.no_shift) - 1); base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
   }
+  const int64_t base_in = P.use_in_off ? P.in_off[co] + (int64_t)b * P.blk_stride : base, base_out = P.use_out_off ? P.out_off[co] + (int64_t)b * P.blk_stride : base;
   const bool heavy = CORNER && w == (int)(blockIdx.x & (NW - 1));   // this wave also computes tile (XT, XT)
   const int R = P.R, C = MODE == 1 ? min(P.C, P.pl - b * P.C) : P.C;
   const double *__restrict__ T1 = P.T1[c][(o >> P.bit1) & 1] + lane, *__restrict__ T2 = P.T2[c][(o >> P.bit2) & 1] + lane;
@@ -331,8 +334,8 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
         if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + slab_at(r * (int)P.row_stride + c2)) : double2{0.0, 0.0};
         else { stage[u].x = (e < TOT && r < R && c2 < C) ? in[slab_at(r * (int)P.row_stride + c2)] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? in[slab_at(r * (int)P.row_stride + c2 + 1)] : 0.0; }
       }
-      else if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
-      else { const double *src = in + base + (int64_t)r * P.row_stride + c2; stage[u].x = (e < TOT && r < R && c2 < C) ? src[0] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? src[1] : 0.0; }
+      else if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base_in + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
+      else { const double *src = in + base_in + (int64_t)r * P.row_stride + c2; stage[u].x = (e < TOT && r < R && c2 < C) ? src[0] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? src[1] : 0.0; }
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) { const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP); if (e < TOT) *reinterpret_cast<double2 *>(&L[r * LD1 + c2]) = stage[u]; }
@@ -403,7 +406,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   if constexpr (MODE == 1) {
     // rows of this wave's tiles: tile row w (and the shared row XT); columns: tile column of the accumulator.  One entry at a time (sched_barrier), otherwise the
     // reciprocal sequences of all of them pile up in registers
-    const double *lamz = P.lam_z[c][(o >> 2) & 1], *bx = P.bxy + (int64_t)(4 * c + (o & 3)) * P.pl;
+    const double *lamz = P.lam_z[c][(o >> 2) & 1], *bx = P.bxy + (int64_t)(P.bxy_cmul * c + (o & 3)) * P.pl;
     const double czc = P.cz[c];
     double lzw[4], lzx[4];
 #pragma unroll
@@ -445,7 +448,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
     for (int q = 0; q < 4; ++q) {
       const int r = 16 * tr + 4 * q + kq, cc = 16 * tc + j;
       if (MODE == 0 && P.slab_io == 1) { if (r < R && cc < C && b < P.store_planes) out[slab_at(r * (int)P.row_stride + cc)] = acc[a][q]; }
-      else if (r < R && cc < C) out[base + (int64_t)r * P.row_stride + cc] = acc[a][q];
+      else if (r < R && cc < C) out[base_out + (int64_t)r * P.row_stride + cc] = acc[a][q];
     }
   }
   if (P.stamps) {
@@ -586,7 +589,7 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
   P.co_stride = O.co_stride; P.hx = hxp; P.pl = hxp * hy;
-  P.bxy = O.bxy.p; P.gate = gate; P.vec2 = 1; P.no_shift = 3;
+  P.bxy = O.bxy.p; P.gate = gate; P.vec2 = 1; P.no_shift = 3; P.bxy_cmul = 4;
   for (int c = 0; c < 3; ++c) { P.cz[c] = O.coef[c][2]; for (int p = 0; p < 2; ++p) P.lam_z[c][p] = O.lam[c][2][p].p; }
   // pass 1: per z-plane, X[ky][kx] -> Fy (X Fx^T)
   P.mode = 0; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 0; P.bit2 = 1;
@@ -624,7 +627,7 @@ void fdmo_slab_pass(hipStream_t s, const FdmOct &O, int pass, const double *in, 
   auto tiles = [](int n) { return (n + 15) / 16; };
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
-  P.co_stride = O.co_stride; P.hx = hxp; P.pl = hxp * hy; P.bxy = O.bxy.p; P.gate = gate; P.vec2 = 1; P.no_shift = 2;
+  P.co_stride = O.co_stride; P.hx = hxp; P.pl = hxp * hy; P.bxy = O.bxy.p; P.gate = gate; P.vec2 = 1; P.no_shift = 2; P.bxy_cmul = 4;
   for (int c = 0; c < 3; ++c) { P.cz[c] = O.coef[c][2]; for (int p = 0; p < 2; ++p) P.lam_z[c][p] = O.lam[c][2][p].p; }
   if (pass == 2) {
     P.mode = 1; P.R = S.hzg; P.C = S.cw; P.nt_r = tiles(S.hzg); P.nt_c = S.cw / 16; P.kk1 = P.kk2 = ksteps(S.hzg); P.nblk = 1; P.blk_stride = (int64_t)S.hzg * S.cw; P.row_stride = S.cw; P.bit1 = P.bit2 = 2;
@@ -658,7 +661,7 @@ void fdmo_scalar_init(FdmOct &O, const int nn[3], hipStream_t s) {
   for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = nn[d]; hmax = std::max(hmax, nn[d]); }
   O.nt = (hmax + 15) / 16; O.hxp = nn[0];
   O.co_stride = (int64_t)nn[0] * nn[1] * nn[2]; O.n_oct = O.co_stride;
-  O.t.alloc(O.n_oct); O.t.zero(s);
+  O.t.alloc(3 * O.n_oct); O.t.zero(s);      // (scratch for up to three right-hand sides at once)
 }
 void fdmo_scalar_upload_dir(FdmOct &O, int dir, const std::vector<double> &S, const std::vector<double> &lam, int n) {   // S: n x n row-major, columns = M-orthonormal eigenvectors
   if (n != (O.slab.on && dir == 2 ? O.slab.ng : O.n[dir])) throw Error("fdmo_scalar_upload_dir: line length mismatch");
@@ -674,23 +677,32 @@ void fdmo_scalar_upload_dir(FdmOct &O, int dir, const std::vector<double> &S, co
 static const double *scalar_table(hipStream_t s, FdmOct &O, double a, double kappa);
 // z = (a M + kappa K)^-1 g; the x / y share a + kappa (lam_x + lam_y) of the eigenvalue sums is tabulated per plane position, one table per (a, kappa)
 void fdmo_scalar_apply(hipStream_t s, FdmOct &O, double a, double kappa, const double *g, double *z, const PcgScalars *gate) {
+  const double *gs[1] = {g}; double *zs[1] = {z};
+  fdmo_scalar_apply_many(s, O, a, kappa, 1, gs, zs, gate);
+}
+// the same for up to three right-hand sides in separate vectors: one set of three launches with 3 x the workgroups (the Q1 systems of config 4 fill less than a third of the chip)
+void fdmo_scalar_apply_many(hipStream_t s, FdmOct &O, double a, double kappa, int nb, const double *const *g, double *const *z, const PcgScalars *gate) {
+  if (nb < 1 || nb > 3) throw Error("fdmo_scalar_apply_many: 1..3 right-hand sides");
   const int nt = O.nt, hx = O.h[0], hy = O.h[1], hz = O.h[2];
   const double *table = scalar_table(s, O, a, kappa);
   auto tiles = [](int n) { return (n + 15) / 16; };
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
-  P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = table; P.gate = gate; P.vec2 = 0; P.no_shift = 0;
-  P.cz[0] = kappa; P.lam_z[0][0] = O.lam[0][2][0].p;
+  P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = table; P.gate = gate; P.vec2 = 0; P.no_shift = 0; P.bxy_cmul = 0;
+  for (int c = 0; c < nb; ++c) { P.cz[c] = kappa; P.lam_z[c][0] = O.lam[0][2][0].p; P.in_off[c] = g[c] - g[0]; P.out_off[c] = z[c] - z[0]; }
   P.mode = 0; P.R = hy; P.C = hx; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hx * hy; P.row_stride = hx; P.bit1 = 0; P.bit2 = 1;
-  P.T1[0][0] = O.fwd[0][0][0].p; P.T2[0][0] = O.fwd[0][1][0].p;
-  launch_pass_nt(s, nt, P, P.nblk, g, O.t.p);
+  for (int c = 0; c < nb; ++c) { P.T1[c][0] = O.fwd[0][0][0].p; P.T2[c][0] = O.fwd[0][1][0].p; }
+  P.use_in_off = 1; P.use_out_off = 0;
+  launch_pass_nt(s, nt, P, nb * P.nblk, g[0], O.t.p);
   const int cw = 16 * std::min(nt, 4);
   P.mode = 1; P.R = hz; P.C = cw; P.nt_r = tiles(hz); P.nt_c = cw / 16; P.kk1 = ksteps(hz); P.kk2 = ksteps(hz); P.nblk = (hx * hy + cw - 1) / cw; P.blk_stride = cw; P.row_stride = (int64_t)hx * hy; P.bit1 = 2; P.bit2 = 2;
-  P.T1[0][0] = O.fwd[0][2][0].p; P.T2[0][0] = O.bwd[0][2][0].p;
-  launch_pass_nt(s, nt, P, P.nblk, O.t.p, O.t.p);
+  for (int c = 0; c < nb; ++c) { P.T1[c][0] = O.fwd[0][2][0].p; P.T2[c][0] = O.bwd[0][2][0].p; }
+  P.use_in_off = 0;
+  launch_pass_nt(s, nt, P, nb * P.nblk, O.t.p, O.t.p);
   P.mode = 2; P.R = hy; P.C = hx; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hy); P.kk2 = ksteps(hx); P.nblk = hz; P.blk_stride = (int64_t)hx * hy; P.row_stride = hx; P.bit1 = 1; P.bit2 = 0;
-  P.T1[0][0] = O.bwd[0][1][0].p; P.T2[0][0] = O.bwd[0][0][0].p;
-  launch_pass_nt(s, nt, P, P.nblk, O.t.p, z);
+  for (int c = 0; c < nb; ++c) { P.T1[c][0] = O.bwd[0][1][0].p; P.T2[c][0] = O.bwd[0][0][0].p; }
+  P.use_out_off = 1;
+  launch_pass_nt(s, nt, P, nb * P.nblk, O.t.p, z[0]);
 }
 
 static const double *scalar_table(hipStream_t s, FdmOct &O, double a, double kappa) {
@@ -706,7 +718,7 @@ void fdmo_scalar_slab_pass(hipStream_t s, FdmOct &O, int pass, double a, double 
   auto tiles = [](int n) { return (n + 15) / 16; };
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
-  P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = scalar_table(s, O, a, kappa); P.vec2 = 0; P.no_shift = 0;
+  P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = scalar_table(s, O, a, kappa); P.vec2 = 0; P.no_shift = 0; P.bxy_cmul = 0;
   P.cz[0] = kappa; P.lam_z[0][0] = O.lam[0][2][0].p;
   if (pass == 2) {
     P.mode = 1; P.R = S.ng; P.C = S.cw; P.nt_r = tiles(S.ng); P.nt_c = S.cw / 16; P.kk1 = P.kk2 = ksteps(S.ng); P.nblk = 1; P.blk_stride = (int64_t)S.hzg * S.cw; P.row_stride = S.cw; P.bit1 = P.bit2 = 2;

@@ -84,8 +84,13 @@ __device__ inline double wave_dn1(double v) {
 // rows of the tile handled by wave w (both of one parity); waves w, w+4, w+8, w+12 share a SIMD, so the tables give every SIMD
 // a similar mix of vertex rows (5-point y-band), mid rows (3-point) and halo rows (z-stage only)
 __device__ const signed char kRows64[16] = {2, 4, 6, 8, 3, 5, 7, 9, 10, 11, 12, 13, 1, 0, 15, 14};
-__device__ const signed char kRows32a[16] = {2, 6, 10, 14, 3, 7, 11, 15, 18, 22, 26, 27, 19, 23, 0, 1};
-__device__ const signed char kRows32b[16] = {4, 8, 12, 16, 5, 9, 13, 17, 20, 24, 28, 29, 21, 25, 30, 31};
+#define PORO_ROWS32A {2, 6, 10, 14, 3, 7, 11, 15, 18, 22, 26, 27, 19, 23, 0, 1}
+#define PORO_ROWS32B {4, 8, 12, 16, 5, 9, 13, 17, 20, 24, 28, 29, 21, 25, 30, 31}
+__device__ const signed char kRows32a[16] = PORO_ROWS32A;
+__device__ const signed char kRows32b[16] = PORO_ROWS32B;
+// the plane loop is specialised on the row parity of a wave and holds workgroup barriers inside both instantiations: the two rows of a wave must have the same parity
+constexpr bool rows32_same_parity() { constexpr signed char a[16] = PORO_ROWS32A, b[16] = PORO_ROWS32B; for (int i = 0; i < 16; ++i) if ((a[i] ^ b[i]) & 1) return false; return true; }
+static_assert(rows32_same_parity(), "kRows32a / kRows32b: the two rows of a wave differ in parity");
 
 // hardware-bounds-checked buffer access (raw buffer, stride 0): a lane whose byte offset lies outside the buffer loads 0 / stores nothing, so
 // the tile halo, the domain edge and the Dirichlet-mask conditions become OFFSETS instead of branches and the plane body stays one basic block
@@ -111,7 +116,7 @@ __device__ __forceinline__ void kron_tile(const KronArgs &a, const double *__res
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lx = lane % TXN;
   const int ra = RPW == 1 ? kRows64[w] : kRows32a[w], rb = RPW == 1 ? ra : kRows32b[w];
   const int r = (RPW == 2 && lane >= TXN) ? rb : ra;
-  const bool odd_row = (ra & 1) != 0, halo_wave = ra < 2 || ra > TYR - 3;
+  const bool odd_row = (__builtin_amdgcn_readfirstlane(ra) & 1) != 0, halo_wave = ra < 2 || ra > TYR - 3;   // (scalar: the parity branch below is wave-uniform by construction, and the barriers inside it are reached by every wave in the same order)
   const int j = Y0 + r, i = X0 + lx;
   const bool even_i = (lx & 1) == 0;
   const bool vj = j >= 0 && j < NY, vn = vj && i >= 0 && i < NX;

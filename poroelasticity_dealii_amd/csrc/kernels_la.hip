@@ -398,6 +398,20 @@ void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, cons
 void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z) {
   if (n_rows) hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, zc, z, g, dinv, inert, omega);
 }
+struct ManyPairs { const double *y[3], *b[3]; };
+__global__ void __launch_bounds__(kBlock) k_residual_norms_many(ManyPairs V, int nb, int64_t n, double *partials) {
+  __shared__ double sh[5];
+  for (int e = 0; e < nb; ++e) {
+    double rr = 0, bb = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) { const double bv = V.b[e][i], r = V.y[e][i] - bv; rr = fma(r, r, rr); bb = fma(bv, bv, bb); }
+    rr = block_sum(rr, sh); bb = block_sum(bb, sh);
+    store_partial(partials + (size_t)(2 * e) * kMaxPartials, rr); store_partial(partials + (size_t)(2 * e + 1) * kMaxPartials, bb);
+  }
+}
+void la_residual_norms_many(hipStream_t s, int nb, const double *const *y, const double *const *b, int64_t n, double *partials) {
+  ManyPairs V{}; for (int e = 0; e < nb; ++e) { V.y[e] = y[e]; V.b[e] = b[e]; }
+  hipLaunchKernelGGL(k_residual_norms_many, reduce_grid(n), kBlock, 0, s, V, nb, n, partials);
+}
 void la_post(hipStream_t s, Mailbox *mb, unsigned long long seq, const double *src, int n, const PcgScalars *sc) { hipLaunchKernelGGL(k_post, 1, 64, 0, s, mb, seq, src, n, sc); }
 void la_fill(hipStream_t s, double *x, double v, int64_t n) { if (n) hipLaunchKernelGGL(k_fill, grid_for(n), kBlock, 0, s, x, v, n); }
 // device-to-device copy as a kernel: hipMemcpyAsync costs the host ~50 us per call (measured between the back-to-back copies of poro_state_restore), a launch ~5 us

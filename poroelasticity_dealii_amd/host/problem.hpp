@@ -124,6 +124,13 @@ template <int dim> class StrainProjector {
     std::vector<int32_t> tc(tensor_components.begin(), tensor_components.end());
     poro_host::check(poro_proj_assemble_rhs(ctx, tc.data(), (int32_t)tc.size()), "proj_assemble_rhs");
   }
+  void solve_projection_systems(const std::vector<int32_t> &rhs_entries, std::vector<poro_solve_info> &infos) {
+    infos.assign(rhs_entries.size(), poro_solve_info{});
+    const int rc = poro_proj_solve_many(ctx, rhs_entries.data(), (int32_t)rhs_entries.size(), &control, infos.data());
+    poro_host::check(rc, "proj_solve_many");
+    if (!infos.empty()) last = infos.back();
+    if (rc > 0) throw poro_host::NoConvergence("StrainProjector::solve_projection_systems", last.iterations, last.final_residual);
+  }
   void solve_projection_system(int rhs_entry) {            // :201-232
     const int rc = poro_proj_solve(ctx, rhs_entry, &control, &last);
     poro_host::check(rc, "proj_solve");
@@ -174,10 +181,11 @@ template <int dim> class PoroElasticProblem {
   }
   void get_normal_strain_components() {                    // :153-164
     strain_projector.assemble_projection_rhs(strain_tensor_volumetric_components);
-    for (const auto &comp : strain_tensor_volumetric_components) {
-      strain_projector.solve_projection_system(tensor_indexer.entryIndex(comp));
-      work.cg_proj += strain_projector.last.iterations; work.apply_p += strain_projector.last.operator_applications;
-    }
+    // the loop of :157-163 over the volumetric components in one library call (solved together where the library can, entry by entry otherwise)
+    std::vector<int32_t> entries; for (const auto &comp : strain_tensor_volumetric_components) entries.push_back(tensor_indexer.entryIndex(comp));
+    std::vector<poro_solve_info> infos(entries.size());
+    strain_projector.solve_projection_systems(entries, infos);
+    for (const auto &li : infos) { work.cg_proj += li.iterations; work.apply_p += li.operator_applications; }
   }
   void get_volumetric_strain() { check(poro_get_volumetric_strain(ctx), "get_volumetric_strain"); }   // :179-186
   // :167-176.  The reference never assembles the shear right-hand sides (assemble_projection_rhs is only called with the volumetric

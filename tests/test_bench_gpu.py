@@ -92,10 +92,11 @@ def test_two_rank_rehearsal():
     assert "8x8x8" in d["config"]["workload"]                      # strong scaling: the BASELINE mesh itself is cut into slabs
     assert d["weak_scaling_line"]["cells"] == "8x8x16" and d["weak_scaling_line"]["value"] > 0     # the box grown along the partitioned direction
     assert d["work_per_step"]["cg_p"] <= 2 * d["work_per_step"]["residual_p"]     # distributed fast diagonalisation in use
-    # single-reduction PCG: one all-reduce per CG iteration of any system (+ one per finished solve, per residual norm and per reported vector norm), and one grouped
-    # neighbour exchange per operator application / assembled vector (the round-1 recurrence needed two all-reduces per iteration)
+    # pressure / projection systems: single-reduction PCG, one all-reduce per CG iteration (+ one per finished solve, per residual norm and per reported vector norm);
+    # displacement system with the block fast diagonalisation in quadrant form: SolverCG's own recurrence on the device-side scalars, two all-reduces per iteration
+    # (d.Ad, then g.g with g.z) + one set at the start; one grouped neighbour exchange per operator application / assembled vector
     w, fam = d["work_per_step"], d["kernel_only"]["launches_by_family"]
-    its = w["cg_u"] + w["cg_p"] + w["cg_proj"]; solves = 1 + w["residual_p"] + 3
+    its = 2 * w["cg_u"] + w["cg_p"] + w["cg_proj"]; solves = 1 + w["residual_p"] + 3
     assert fam["allreduce"] <= its + 2 * solves + w["residual_p"] + 8, (fam, w)
     assert fam["halo_exchange"] <= w["apply_u"] + w["apply_p"] + 2 * solves + 24, (fam, w)
 

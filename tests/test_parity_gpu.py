@@ -177,6 +177,15 @@ def test_fast_diagonalisation_preconditioner(pair):
         rc0, _ = O.proj_solve(e, rel_tol=1e-13); rc, info = G.proj_solve(e, rel_tol=1e-8, prec=pk.PREC_FDM)
         assert rc0 == 0 and rc == 0 and info.iterations <= 2
         assert rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
+    # all entries in one call (poro_proj_solve_many): solved directly and together where the library has the fused form (3D boxes of <= 80 vertices per line, matrix-free
+    # context), entry by entry otherwise - the same strains either way
+    ents = [0, 2] if G.dim == 2 else [0, 3, 5]
+    for e in ents:
+        G.fill(pk.VEC_STRAIN0 + e, 0.0)
+    rc, infos = G.proj_solve_many(ents, rel_tol=1e-8, prec=pk.PREC_FDM)
+    assert rc == 0 and all(i.converged and i.final_residual <= 1e-8 * max(i.initial_residual, 1e-300) for i in infos), [(i.iterations, i.final_residual) for i in infos]
+    for e in ents:
+        assert rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
     # the displacement system's block form (tests/test_fdm_u_gpu.py) also serves the assembled-CSR operator
     O.disp_assemble_system(True); G.disp_assemble_system(True)
     O.fill(pk.VEC_U, 0.0); G.fill(pk.VEC_U, 0.0)
