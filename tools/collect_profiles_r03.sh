@@ -48,15 +48,21 @@ echo "[3] bench lines done"
 python3 $ROOT/bench.py --dim 3 --degree 1 --cells 99 --no-cpu-baseline --config5-steps 20 > $OUT/${TAG}_bench_line_c3.json 2>/dev/null
 python3 $ROOT/bench.py --dim 2 --cells 336 --no-cpu-baseline --config5-steps 20 > $OUT/${TAG}_bench_line_c2.json 2>/dev/null
 echo "[4] configs 2, 3 done"
-# 5. general matrix-free kernel without the box tag: 1.17 M and 9.1 M dofs, statistics + traffic at the large size
+# 5. general matrix-free kernel without the box tag: 1.17 M and 9.1 M dofs (the kernel source did not change after these were taken: only if asked for)
+if [ -n "$WITH_MFG" ]; then
 python3 $ROOT/tools/mfg_bench.py 36 2 > $OUT/${TAG}_mfg_bench_36.json 2>/dev/null
 python3 $ROOT/tools/mfg_bench.py 72 2 > $OUT/${TAG}_mfg_bench_72.json 2>/dev/null
 REPS=10 bash $ROOT/tools/kernel_counters.sh mfg_72 k_mfg3_sf tools/mfg_bench.py 72 2 > /dev/null 2>&1
 cp $ROOT/gpurun_out/counters_mfg_72/summary.txt $OUT/${TAG}_mfg_counters_72.txt
+fi
 echo "[5] general kernel done"
-# 6. the partitioned code path on one RCCL rank next to the single-rank path
-python3 $ROOT/tools/partitioned_path_1rank.py 72 > $OUT/${TAG}_partitioned_path_1rank.txt 2>&1
+# 6. the partitioned code path on one RCCL rank next to the single-rank path (+ its kernel statistics), the rank-thread rehearsals of config 4's partitions
+python3 $ROOT/tools/partitioned_path_1rank.py 72 noforce > $OUT/${TAG}_partitioned_path_1rank.txt 2>&1
 python3 $ROOT/tools/partitioned_path_1rank.py 72 force >> $OUT/${TAG}_partitioned_path_1rank.txt 2>&1
+bash $ROOT/tools/slab_probe.sh 72 > $OUT/${TAG}_partitioned_path_1rank_kernels.txt 2>&1
+python3 $ROOT/tools/rank_threads.py --ranks 8 --cells 72 --steps 3 --json $OUT/${TAG}_rank_threads_8x9_block_fdm.json > /dev/null 2>&1
+python3 $ROOT/tools/rank_threads.py --ranks 2 --cells 72 --steps 3 --json $OUT/${TAG}_rank_threads_2x36_block_fdm.json > /dev/null 2>&1
+echo "[6] partitioned path done"
 # 7. SQ counters of the structured operator
 bash $ROOT/tools/sq_counters.sh $TAG > /dev/null 2>&1 && cp $ROOT/gpurun_out/sq_$TAG/summary.txt $OUT/${TAG}_sq_counters_kron3.txt
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/ktrace
