@@ -271,9 +271,15 @@ template <int NT> struct PassGeom {
 //     mod 4, so that over the items every SIMD gets the same share (6.25 tiles per wave on average; the two GEMM bodies - with and without the seventh tile - are
 //     separate branch-free instruction streams);
 //   pass 2 (lines are independent): chunks of 64 columns = 5 x 4 tiles, wave w owns (w, 0..3) and (4, w): five tiles each, nothing left over.
-template <int NT, int MODE>
+// GENERAL = false: the octant form on one rank (24 blocks, aligned rows, no exchange buffer, no per-block offsets) with those switches folded at compile time;
+// GENERAL = true: everything else (quadrant form on slabs, scalar systems, batched right-hand sides)
+template <int NT, int MODE, bool GENERAL>
 __global__ void __launch_bounds__(64 * (NT < 4 ? NT : 4))
 k_fdmo_pass(OctPass P, const double *in, double *out) {
+  // (the kernel argument stays in the kernarg segment - a modified copy would live in scratch because of its dynamically indexed members)
+  const int f_vec2 = GENERAL ? P.vec2 : 1, f_slab_z = GENERAL ? P.slab_z : 0, f_slab_io = GENERAL ? P.slab_io : 0, f_use_in = GENERAL ? P.use_in_off : 0, f_use_out = GENERAL ? P.use_out_off : 0,
+            f_no_shift = GENERAL ? P.no_shift : 3, f_bxy_cmul = GENERAL ? P.bxy_cmul : 4;
+  const int64_t *const f_row_in = GENERAL ? P.row_in : nullptr;
   typedef PassGeom<NT> Gm;
   constexpr int NW = NT < 4 ? NT : 4;                        // waves
   constexpr bool EXTRA = NT > NW;                            // NT == 5: the fifth tile row / column is shared out
@@ -290,30 +296,30 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   int b, c, o, co = 0; int64_t base;
-  if (MODE == 1 && P.slab_z) {
-    const int G = P.chunk0 + (int)(blockIdx.x >> (P.slab_z - 1)), cq = G / P.nchunk;
+  if (MODE == 1 && f_slab_z) {
+    const int G = P.chunk0 + (int)(blockIdx.x >> (f_slab_z - 1)), cq = G / P.nchunk;
     if (G >= P.chunk_total) return;                                  // (the last rank's share may be short; workgroup-uniform, before any barrier)
-    b = G - cq * P.nchunk; c = cq >> 2; o = (cq & 3) | ((blockIdx.x & (P.slab_z - 1)) << 2); base = (int64_t)blockIdx.x * P.blk_stride;
+    b = G - cq * P.nchunk; c = cq >> 2; o = (cq & 3) | ((blockIdx.x & (f_slab_z - 1)) << 2); base = (int64_t)blockIdx.x * P.blk_stride;
   } else {
     co = blockIdx.x / P.nblk;
-    b = blockIdx.x % P.nblk; c = co >> P.no_shift; o = co & ((1 << P.no_shift) - 1); base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
+    b = blockIdx.x % P.nblk; c = co >> f_no_shift; o = co & ((1 << f_no_shift) - 1); base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
   }
-  const int64_t base_in = P.use_in_off ? P.in_off[co] + (int64_t)b * P.blk_stride : base, base_out = P.use_out_off ? P.out_off[co] + (int64_t)b * P.blk_stride : base;
+  const int64_t base_in = f_use_in ? P.in_off[co] + (int64_t)b * P.blk_stride : base, base_out = f_use_out ? P.out_off[co] + (int64_t)b * P.blk_stride : base;
   const bool heavy = CORNER && w == (int)(blockIdx.x & (NW - 1));   // this wave also computes tile (XT, XT)
   const int R = P.R, C = MODE == 1 ? min(P.C, P.pl - b * P.C) : P.C;
   const double *__restrict__ T1 = P.T1[c][(o >> P.bit1) & 1] + lane, *__restrict__ T2 = P.T2[c][(o >> P.bit2) & 1] + lane;
   // slab form: address of plane position `col` of this block in the exchange buffer
   // (a block's columns lie in at most two shares when a share is at least a block long - up to 12 ranks: the two bases are wave-uniform scalars)
   int slab_q0 = 0, slab_sw = 0; int64_t slab_base[2] = {0, 0};
-  if (MODE != 1 && P.slab_io) {
+  if (MODE != 1 && f_slab_io) {
     const int X0 = co * P.col_unit; slab_q0 = X0 / P.scols; slab_sw = (slab_q0 + 1) * P.scols - X0;
-    for (int k = 0; k < 2; ++k) slab_base[k] = (int64_t)X0 + (int64_t)(slab_q0 + k) * P.dest_stride + (int64_t)b * P.scols + ((P.slab_io == 2 || slab_q0 + k == P.rank) ? P.recv_off : 0);
+    for (int k = 0; k < 2; ++k) slab_base[k] = (int64_t)X0 + (int64_t)(slab_q0 + k) * P.dest_stride + (int64_t)b * P.scols + ((f_slab_io == 2 || slab_q0 + k == P.rank) ? P.recv_off : 0);
   }
   auto slab_at = [&](int col) -> int64_t {
     if (P.scols >= P.col_unit) return (int64_t)col + (col >= slab_sw ? slab_base[1] : slab_base[0]);
     const int X = co * P.col_unit + col;
     int q = (int)((float)X * P.inv_scols); q -= q * P.scols > X; q += (q + 1) * P.scols <= X;      // X / scols (X < 2^24)
-    return (int64_t)X + (int64_t)q * P.dest_stride + (int64_t)b * P.scols + ((P.slab_io == 2 || q == P.rank) ? P.recv_off : 0);
+    return (int64_t)X + (int64_t)q * P.dest_stride + (int64_t)b * P.scols + ((f_slab_io == 2 || q == P.rank) ? P.recv_off : 0);
   };
   auto stamp = [&](int k) { if (P.stamps && tid == 0) P.stamps[(int64_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime(); };
   stamp(0);
@@ -325,16 +331,16 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP);
-      if (MODE == 1 && P.row_in) {             // gathered planes -> parity part of the global line: e_k = v_k + v_k', o_k = v_k - v_k' (centre plane: e = v, o = 0)
-        const bool ok = e < TOT && r < R && c2 < C, split = P.slab_z == 2; const int rr = ok ? r : 0, mr = split ? P.ng - 1 - rr : rr; const int64_t cb = (int64_t)(blockIdx.x >> (P.slab_z - 1)) * P.C + c2;
-        const double2 lo = ok ? *reinterpret_cast<const double2 *>(in + P.row_in[rr] + cb) : double2{0.0, 0.0}, hi = (ok && mr != rr) ? *reinterpret_cast<const double2 *>(in + P.row_in[mr] + cb) : double2{0.0, 0.0};
+      if (MODE == 1 && f_row_in) {             // gathered planes -> parity part of the global line: e_k = v_k + v_k', o_k = v_k - v_k' (centre plane: e = v, o = 0)
+        const bool ok = e < TOT && r < R && c2 < C, split = f_slab_z == 2; const int rr = ok ? r : 0, mr = split ? P.ng - 1 - rr : rr; const int64_t cb = (int64_t)(blockIdx.x >> (f_slab_z - 1)) * P.C + c2;
+        const double2 lo = ok ? *reinterpret_cast<const double2 *>(in + f_row_in[rr] + cb) : double2{0.0, 0.0}, hi = (ok && mr != rr) ? *reinterpret_cast<const double2 *>(in + f_row_in[mr] + cb) : double2{0.0, 0.0};
         const bool odd = split && (blockIdx.x & 1);
         stage[u].x = odd ? (mr != rr ? lo.x - hi.x : 0.0) : lo.x + hi.x; stage[u].y = odd ? (mr != rr ? lo.y - hi.y : 0.0) : lo.y + hi.y;
-      } else if (MODE == 2 && P.slab_io == 2) {
-        if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + slab_at(r * (int)P.row_stride + c2)) : double2{0.0, 0.0};
+      } else if (MODE == 2 && f_slab_io == 2) {
+        if (f_vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + slab_at(r * (int)P.row_stride + c2)) : double2{0.0, 0.0};
         else { stage[u].x = (e < TOT && r < R && c2 < C) ? in[slab_at(r * (int)P.row_stride + c2)] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? in[slab_at(r * (int)P.row_stride + c2 + 1)] : 0.0; }
       }
-      else if (P.vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base_in + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
+      else if (f_vec2) stage[u] = (e < TOT && r < R && c2 < C) ? *reinterpret_cast<const double2 *>(in + base_in + (int64_t)r * P.row_stride + c2) : double2{0.0, 0.0};
       else { const double *src = in + base_in + (int64_t)r * P.row_stride + c2; stage[u].x = (e < TOT && r < R && c2 < C) ? src[0] : 0.0; stage[u].y = (e < TOT && r < R && c2 + 1 < C) ? src[1] : 0.0; }
     }
 #pragma unroll
@@ -406,7 +412,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   if constexpr (MODE == 1) {
     // rows of this wave's tiles: tile row w (and the shared row XT); columns: tile column of the accumulator.  One entry at a time (sched_barrier), otherwise the
     // reciprocal sequences of all of them pile up in registers
-    const double *lamz = P.lam_z[c][(o >> 2) & 1], *bx = P.bxy + (int64_t)(P.bxy_cmul * c + (o & 3)) * P.pl;
+    const double *lamz = P.lam_z[c][(o >> 2) & 1], *bx = P.bxy + (int64_t)(f_bxy_cmul * c + (o & 3)) * P.pl;
     const double czc = P.cz[c];
     double lzw[4], lzx[4];
 #pragma unroll
@@ -447,7 +453,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = 16 * tr + 4 * q + kq, cc = 16 * tc + j;
-      if (MODE == 0 && P.slab_io == 1) { if (r < R && cc < C && b < P.store_planes) out[slab_at(r * (int)P.row_stride + cc)] = acc[a][q]; }
+      if (MODE == 0 && f_slab_io == 1) { if (r < R && cc < C && b < P.store_planes) out[slab_at(r * (int)P.row_stride + cc)] = acc[a][q]; }
       else if (r < R && cc < C) out[base_out + (int64_t)r * P.row_stride + cc] = acc[a][q];
     }
   }
@@ -460,9 +466,16 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
 template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid((unsigned)n_items), block(64 * (NT < 4 ? NT : 4));
   // (events attached to the dispatch itself: the kernel's own duration, as rocprofv3 reports it)
-  if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0>), grid, block, 0, s, e0, e1, 0, P, in, out);
-  else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1>), grid, block, 0, s, e0, e1, 0, P, in, out);
-  else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2>), grid, block, 0, s, e0, e1, 0, P, in, out);
+  const bool general = !(P.vec2 == 1 && P.slab_z == 0 && P.slab_io == 0 && !P.row_in && !P.use_in_off && !P.use_out_off && P.no_shift == 3 && P.bxy_cmul == 4);
+  if (general) {
+    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, true>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, true>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, true>), grid, block, 0, s, e0, e1, 0, P, in, out);
+  } else {
+    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, false>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, false>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, false>), grid, block, 0, s, e0, e1, 0, P, in, out);
+  }
 }
 void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const double *in, double *out, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   switch (nt) {
