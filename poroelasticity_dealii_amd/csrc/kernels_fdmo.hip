@@ -271,15 +271,17 @@ template <int NT> struct PassGeom {
 //     mod 4, so that over the items every SIMD gets the same share (6.25 tiles per wave on average; the two GEMM bodies - with and without the seventh tile - are
 //     separate branch-free instruction streams);
 //   pass 2 (lines are independent): chunks of 64 columns = 5 x 4 tiles, wave w owns (w, 0..3) and (4, w): five tiles each, nothing left over.
-// GENERAL = false: the octant form on one rank (24 blocks, aligned rows, no exchange buffer, no per-block offsets) with those switches folded at compile time;
-// GENERAL = true: everything else (quadrant form on slabs, scalar systems, batched right-hand sides)
-template <int NT, int MODE, bool GENERAL>
+// VAR = 0: the octant form on one rank (24 blocks, aligned rows, no exchange buffer, no per-block offsets) with those switches folded at compile time;
+// VAR = 1: the quadrant form of the displacement system on slabs (pass 1 stores into / pass 3 loads from the exchange buffer, pass 2 forms the parity parts on load), likewise;
+// VAR = 2: everything else by run-time switches (scalar systems, batched right-hand sides)
+template <int NT, int MODE, int VAR>
 __global__ void __launch_bounds__(64 * (NT < 4 ? NT : 4))
 k_fdmo_pass(OctPass P, const double *in, double *out) {
   // (the kernel argument stays in the kernarg segment - a modified copy would live in scratch because of its dynamically indexed members)
-  const int f_vec2 = GENERAL ? P.vec2 : 1, f_slab_z = GENERAL ? P.slab_z : 0, f_slab_io = GENERAL ? P.slab_io : 0, f_use_in = GENERAL ? P.use_in_off : 0, f_use_out = GENERAL ? P.use_out_off : 0,
-            f_no_shift = GENERAL ? P.no_shift : 3, f_bxy_cmul = GENERAL ? P.bxy_cmul : 4;
-  const int64_t *const f_row_in = GENERAL ? P.row_in : nullptr;
+  constexpr bool GENERAL = VAR == 2, SLAB = VAR == 1;
+  const int f_vec2 = GENERAL ? P.vec2 : 1, f_slab_z = GENERAL ? P.slab_z : (SLAB && MODE == 1 ? 2 : 0), f_slab_io = GENERAL ? P.slab_io : (SLAB && MODE == 0 ? 1 : SLAB && MODE == 2 ? 2 : 0),
+            f_use_in = GENERAL ? P.use_in_off : 0, f_use_out = GENERAL ? P.use_out_off : 0, f_no_shift = GENERAL ? P.no_shift : (SLAB ? 2 : 3), f_bxy_cmul = GENERAL ? P.bxy_cmul : 4;
+  const int64_t *const f_row_in = (GENERAL || (SLAB && MODE == 1)) ? P.row_in : nullptr;
   typedef PassGeom<NT> Gm;
   constexpr int NW = NT < 4 ? NT : 4;                        // waves
   constexpr bool EXTRA = NT > NW;                            // NT == 5: the fifth tile row / column is shared out
@@ -466,15 +468,21 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
 template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid((unsigned)n_items), block(64 * (NT < 4 ? NT : 4));
   // (events attached to the dispatch itself: the kernel's own duration, as rocprofv3 reports it)
-  const bool general = !(P.vec2 == 1 && P.slab_z == 0 && P.slab_io == 0 && !P.row_in && !P.use_in_off && !P.use_out_off && P.no_shift == 3 && P.bxy_cmul == 4);
-  if (general) {
-    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, true>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, true>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, true>), grid, block, 0, s, e0, e1, 0, P, in, out);
+  const bool plain = P.vec2 == 1 && !P.use_in_off && !P.use_out_off && P.bxy_cmul == 4;
+  const bool oct = plain && P.slab_z == 0 && P.slab_io == 0 && !P.row_in && P.no_shift == 3;
+  const bool slab_u = plain && P.no_shift == 2 && ((P.mode == 0 && P.slab_io == 1 && !P.slab_z) || (P.mode == 1 && P.slab_z == 2 && P.row_in && !P.slab_io) || (P.mode == 2 && P.slab_io == 2 && !P.slab_z));
+  if (oct) {
+    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, 0>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, 0>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, 0>), grid, block, 0, s, e0, e1, 0, P, in, out);
+  } else if (slab_u) {
+    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, 1>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, 1>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, 1>), grid, block, 0, s, e0, e1, 0, P, in, out);
   } else {
-    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, false>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, false>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, false>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, 2>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, 2>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, 2>), grid, block, 0, s, e0, e1, 0, P, in, out);
   }
 }
 void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const double *in, double *out, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
