@@ -109,6 +109,8 @@ struct FdmOct {
   // slab-partitioned form ("quadrant form"): only x and y are split into parities in the CG vectors, Q[c][q = 2 py + px][kz local][ky][kx] (no = 4 blocks per component);
   // the z transform runs on whole global lines after an all-to-all of column chunks, where the z butterfly is applied on the way in / out of the transposed array
   int no = 8;                                     // blocks per component in g, z, t: 8 octants, or 4 quadrants when z is not split locally
+  int nc = 3;                                     // components per node: 3; 2 for the planar (2D) form, which is the quadrant form with a single plane
+  bool planar = false;                            // 2D: the transforms are batched tiled GEMMs over whole (component, quadrant) planes (fwd = row-major h x h matrices F[mode][node])
   int own_z = 0;                                  // local node planes that count in dot products (the upper shared plane belongs to the neighbour)
   struct Slab {
     bool on = false; int n_ranks = 1, rank = 0;
@@ -376,6 +378,11 @@ void la_residual_norms_many(hipStream_t s, int nb, const double *const *y, const
 // slab partitions: nn = LOCAL vertices, the last direction's matrices are uploaded for the GLOBAL line; the three sweeps separately (all-to-alls in between, ctx_prec.hip)
 void fdmo_scalar_init_slab(FdmOct &O, const int nn[3], int rank, const std::vector<int> &node_layers, hipStream_t s);
 void fdmo_scalar_slab_pass(hipStream_t s, FdmOct &O, int pass, double a, double kappa, const double *in, double *out);
+// planar (2D) form: quadrant layout with one plane and 2 components; four batched GEMM launches per application
+bool fdmo_planar_usable(int dim, const int nn[3]);
+void fdmo_init_planar(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s);
+bool fdmo_upload_dir_planar(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn);
+void fdmo_apply_planar(hipStream_t s, const FdmOct &O, const double *g_q, double *z_q, const PcgScalars *gate = nullptr);
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v_nodal, double *q_oct);   // q = H v (node-interleaved vector -> octant form)
 void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r_oct, double *v_nodal);     // v = H^-1-form of the backward transform: v_k = a + b, v_k' = a - b
 // the vector kernels of pcg() with g / z in octant form (same device-side scalar protocol as their nodal counterparts in kernels_la.hip)

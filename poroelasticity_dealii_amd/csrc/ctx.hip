@@ -442,6 +442,7 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
         // g, z in octant form: three contiguous sweeps; inside the iteration the launches are gated on the device-side "solve finished" flag (before
         // pcg_scalars_start it still holds the previous solve's state)
         if (oct && oct->slab.on) fdm_precondition_u_slab(c, g, z, in_iteration ? c->scal.p : nullptr);
+        else if (oct && oct->planar) { Timed tm(c, "precondition_u_fdm"); fdmo_apply_planar(c->stream, *oct, g, z, in_iteration ? c->scal.p : nullptr); }
         else if (oct) {
           Timed tm(c, "precondition_u_fdm");
           if (c->timing && c->timers["fdm_u_pass1"].sample(c->timing_stride)) {     // the three transform dispatches individually (per-kernel roofline of the bench)
@@ -758,7 +759,7 @@ int poro_apply_preconditioner_u(poro_ctx *c, int32_t preconditioner, const doubl
       build_fdm_u(c);
       FdmOct &O = c->fdm_oct;
       // octant form where the solver uses it: butterflies outside (H, H'), the three transform passes in between - the timed part, as inside PCG
-      auto once = [&]() { if (O.built && O.slab.on) fdm_precondition_u_slab(c, O.g.p, O.z.p, nullptr); else if (O.built) fdmo_apply(s, O, O.g.p, O.z.p, O.t.p); else fdm_precondition_u(c, g.p, z.p); };
+      auto once = [&]() { if (O.built && O.slab.on) fdm_precondition_u_slab(c, O.g.p, O.z.p, nullptr); else if (O.built && O.planar) fdmo_apply_planar(s, O, O.g.p, O.z.p); else if (O.built) fdmo_apply(s, O, O.g.p, O.z.p, O.t.p); else fdm_precondition_u(c, g.p, z.p); };
       if (O.built) fdmo_from_nodal(s, O, g.p, O.g.p);
       once();
       if (O.built) fdmo_to_nodal(s, O, O.z.p, z.p);

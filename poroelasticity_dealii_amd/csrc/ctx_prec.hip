@@ -271,9 +271,13 @@ void build_fdm_u(poro_ctx *c) {
   // octant form (kernels_fdmo.hip): one rank, 3D, every direction mirror-symmetric for every component, half lines of at most 80 entries
   // slab partitions: the quadrant form (x, y split locally; the z butterfly next to the all-to-all) under the same conditions on the GLOBAL line
   bool oct_ok = !F.single && !std::getenv("PORO_FDMU_NO_OCT");
-  { int nn3[3] = {F.nn[0], F.nn[1], F.nn[2]}, sym3[3] = {F.nn[0], F.nn[1], multi ? F.ng : F.nn[2]}; oct_ok = oct_ok && fdmo_usable(dim, sym3);
+  bool planar = false;     // 2D, one rank: the quadrant form with a single plane, transforms as batched GEMMs (lines of any length)
+  { int nn3[3] = {F.nn[0], F.nn[1], F.nn[2]}, sym3[3] = {F.nn[0], F.nn[1], multi ? F.ng : F.nn[2]};
+    planar = dim == 2 && !multi && fdmo_planar_usable(dim, nn3);
+    oct_ok = oct_ok && (planar || fdmo_usable(dim, sym3));
     for (int d = 0; d < dim && oct_ok; ++d) for (int comp = 0; comp < dim; ++comp) oct_ok = oct_ok && F.fix[comp][d][0] == F.fix[comp][d][1];
-    if (oct_ok && !multi) fdmo_init(c->fdm_oct, nn3, F.coef, c->stream);
+    if (oct_ok && planar) fdmo_init_planar(c->fdm_oct, nn3, F.coef, c->stream);
+    else if (oct_ok && !multi) fdmo_init(c->fdm_oct, nn3, F.coef, c->stream);
     if (oct_ok && multi) { std::vector<int> node_layers(F.n_ranks); for (int q = 0; q < F.n_ranks; ++q) node_layers[q] = ku * F.layers[q];
                            fdmo_init_slab(c->fdm_oct, nn3, F.coef, F.rank, node_layers, c->comm.part.has_upper != 0, c->stream); } }
   // eigenpairs per (direction, end conditions); components with the same end conditions share the host work.  A direction takes the even / odd
@@ -293,7 +297,7 @@ void build_fdm_u(poro_ctx *c) {
         FdmuDir &D = global_dir ? F.last_global[comp] : F.dir[comp][d];
         fdmu_upload_dir(D, S[key], lam[key], nnode, global_dir ? false : F.single, allow_split);
         all_split = all_split && D.split;
-        if (oct_ok && attempt == 0) oct_ok = fdmo_upload_dir(c->fdm_oct, comp, d, S[key], lam[key], nnode);
+        if (oct_ok && attempt == 0) oct_ok = planar ? fdmo_upload_dir_planar(c->fdm_oct, comp, d, S[key], lam[key], nnode) : fdmo_upload_dir(c->fdm_oct, comp, d, S[key], lam[key], nnode);
       }
       if (!allow_split || all_split) break;
       allow_split = false;                       // the numerical symmetry check failed for some component: the whole direction in the full form
@@ -301,7 +305,7 @@ void build_fdm_u(poro_ctx *c) {
   }
   c->fdmu_t1.alloc(c->n_u); c->fdmu_t2.alloc(c->n_u); c->fdmu_t1.zero(c->stream); c->fdmu_t2.zero(c->stream);   // (only finite values ever live in the scratch arrays)
   if (!c->wz_u.p) { c->wz_u.alloc(c->n_u); c->wz_u.zero(c->stream); }
-  if (oct_ok) fdmo_finalize(c->fdm_oct);
+  if (oct_ok && !planar) fdmo_finalize(c->fdm_oct);
   c->fdm_oct.built = oct_ok;
   F.built = true;
 }
@@ -345,7 +349,7 @@ void two_level_precondition_u(poro_ctx *c, const double *g, double *z, double om
   double *rc = H->wg_u.p, *zc = H->wz_u.p;                                  // the box context's work vectors (it never solves anything itself)
   la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, dim, g, rc);              // r_H = P^T g
   FdmOct &O = H->fdm_oct;
-  if (O.built) { fdmo_from_nodal(s, O, rc, O.g.p); fdmo_apply(s, O, O.g.p, O.z.p, O.t.p); fdmo_to_nodal(s, O, O.z.p, zc); }
+  if (O.built) { fdmo_from_nodal(s, O, rc, O.g.p); if (O.planar) fdmo_apply_planar(s, O, O.g.p, O.z.p); else fdmo_apply(s, O, O.g.p, O.z.p, O.t.p); fdmo_to_nodal(s, O, O.z.p, zc); }
   else fdm_precondition_u(H, rc, zc);                                         // z_H = blockdiag(A_H)^-1 r_H (zero on the box's Dirichlet faces)
   la_two_level_combine(s, T.p_ptr.p, T.p_col.p, T.p_w.p, T.n_fine, dim, zc, g, c->dinv_u.p, c->cons_u.inert.p, omega, z);
 }

@@ -33,7 +33,7 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-struct OctDims { int nx, ny, nz, hx, hy, hz, hxp; int64_t co; int no, own_z; };   // nodes and half lengths per direction; hxp = row pitch (hx rounded up to even: 16-byte aligned rows, the pad entry stays zero); co = hxp hy hz entries per (component, octant)
+struct OctDims { int nx, ny, nz, hx, hy, hz, hxp; int64_t co; int no, own_z, nc; };   // nodes and half lengths per direction; hxp = row pitch (hx rounded up to even: 16-byte aligned rows, the pad entry stays zero); co = hxp hy hz entries per (component, octant)
 // no = 8: octant form.  no = 4 (slab partitions): z is not split - every z index is "its own mirror image" (hz = nz, parity blocks 0..3 only); own_z = planes that count in dot products
 
 // ---- the 8-point butterfly --------------------------------------------------------------------------------------------------------------
@@ -84,22 +84,22 @@ struct OctPos {
 // vectors contiguously (dof = 3 node + c: 512 contiguous bytes per wave access, ascending for the lower nodes, descending for the mirror images) and through three
 // contiguous streams of every octant array.  (First version: one thread per position, all three components - 8-byte accesses at 24-byte stride: 170 us for the
 // direction update instead of 45.)
-#define PORO_OCT_LOOP(D) for (int64_t t_ = (int64_t)blockIdx.x * kBlock + threadIdx.x; t_ < 3 * (D).co; t_ += (int64_t)gridDim.x * kBlock)
-#define PORO_OCT_DECODE(D) const int64_t idx = t_ / 3; const int c = (int)(t_ - 3 * idx); const OctPos P(D, idx); if (!P.valid) continue;
+#define PORO_OCT_LOOP(D) for (int64_t t_ = (int64_t)blockIdx.x * kBlock + threadIdx.x; t_ < NC * (D).co; t_ += (int64_t)gridDim.x * kBlock)   /* NC = components per node: 3, or 2 for the planar form */
+#define PORO_OCT_DECODE(D) const int64_t idx = t_ / NC; const int c = (int)(t_ - NC * idx); const OctPos P(D, idx); if (!P.valid) continue;
 
 // q = H v: node-interleaved vector (dof = 3 node + c) -> octant form; masked dofs count as zero
-__global__ void __launch_bounds__(kBlock) k_fdmo_from_nodal(OctDims D, const double *__restrict__ v, const uint8_t *__restrict__ inert, double *__restrict__ q) {
+template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_from_nodal(OctDims D, const double *__restrict__ v, const uint8_t *__restrict__ inert, double *__restrict__ q) {
   PORO_OCT_LOOP(D) {
     PORO_OCT_DECODE(D)
     double w[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) { const int64_t dof = P.node[m] * 3 + c; w[m] = (inert && inert[dof]) ? 0.0 : v[dof]; }
+    for (int m = 0; m < 8; ++m) { const int64_t dof = P.node[m] * NC + c; w[m] = (inert && inert[dof]) ? 0.0 : v[dof]; }
     bfly_fwd(w, P.centre);
 #pragma unroll
     for (int o = 0; o < 8; ++o) if (o < D.no) q[(int64_t)(c * D.no + o) * D.co + idx] = w[o];
   }
 }
-__global__ void __launch_bounds__(kBlock) k_fdmo_to_nodal(OctDims D, const double *__restrict__ r, double *__restrict__ v) {
+template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_to_nodal(OctDims D, const double *__restrict__ r, double *__restrict__ v) {
   PORO_OCT_LOOP(D) {
     PORO_OCT_DECODE(D)
     double w[8];
@@ -107,25 +107,25 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_to_nodal(OctDims D, const doubl
     for (int o = 0; o < 8; ++o) w[o] = o < D.no ? r[(int64_t)(c * D.no + o) * D.co + idx] : 0.0;
     bfly_bwd(w, P.centre);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) if (P.live[m]) v[P.node[m] * 3 + c] = w[m];
+    for (int m = 0; m < 8; ++m) if (P.live[m]) v[P.node[m] * NC + c] = w[m];
   }
 }
 
 // ---- CG vector kernels with g, z in octant form (protocol of k_pcg_* in kernels_la.hip) ---------------------------------------------------
 // g = H (A x - b), zero on the inert (Dirichlet) dofs
-__global__ void __launch_bounds__(kBlock) k_fdmo_init_residual(OctDims D, double *__restrict__ g, const double *__restrict__ Ax, const double *__restrict__ b, const uint8_t *__restrict__ inert) {
+template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_init_residual(OctDims D, double *__restrict__ g, const double *__restrict__ Ax, const double *__restrict__ b, const uint8_t *__restrict__ inert) {
   PORO_OCT_LOOP(D) {
     PORO_OCT_DECODE(D)
     double w[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) { const int64_t dof = P.node[m] * 3 + c; w[m] = (inert && inert[dof]) ? 0.0 : Ax[dof] - b[dof]; }
+    for (int m = 0; m < 8; ++m) { const int64_t dof = P.node[m] * NC + c; w[m] = (inert && inert[dof]) ? 0.0 : Ax[dof] - b[dof]; }
     bfly_fwd(w, P.centre);
 #pragma unroll
     for (int o = 0; o < 8; ++o) if (o < D.no) g[(int64_t)(c * D.no + o) * D.co + idx] = w[o];
   }
 }
 // d = -z (nodal); block partials of g.g and g.z
-__global__ void __launch_bounds__(kBlock) k_fdmo_first_direction(OctDims D, double *__restrict__ d, const double *__restrict__ g, const double *__restrict__ z, double *partials) {
+template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_first_direction(OctDims D, double *__restrict__ d, const double *__restrict__ g, const double *__restrict__ z, double *partials) {
   __shared__ double sh[5];
   double gg = 0, gz = 0;
   PORO_OCT_LOOP(D) {
@@ -136,13 +136,13 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_first_direction(OctDims D, doub
     if (P.own) { gg = fma(P.weight, s2, gg); gz += sz; }
     bfly_bwd(w, P.centre);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) if (P.live[m]) d[P.node[m] * 3 + c] = -w[m];
+    for (int m = 0; m < 8; ++m) if (P.live[m]) d[P.node[m] * NC + c] = -w[m];
   }
   gg = block_sum(gg, sh); gz = block_sum(gz, sh);
   store_partial(partials, gg); store_partial(partials + kMaxPartials, gz);
 }
 // g += alpha H (A d) and the partials of g.g (g.z follows in a plain dot of the two octant arrays once z = P^-1 g exists)
-__global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctDims D, PcgScalars *sc, int parity, double *__restrict__ g, const double *__restrict__ h, const uint8_t *__restrict__ inert, const double *partials_dh, double *partials_out, const double *red) {
+template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctDims D, PcgScalars *sc, int parity, double *__restrict__ g, const double *__restrict__ h, const uint8_t *__restrict__ inert, const double *partials_dh, double *partials_out, const double *red) {
   __shared__ double sh[5];
   if (sc->done) return;
   if (sc->finishing) { if (blockIdx.x == 0 && threadIdx.x == 0) sc->done = 1; return; }   // (see k_pcg_update_g_fused)
@@ -153,10 +153,10 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctDims D, PcgScalars 
     PORO_OCT_DECODE(D)
     // inert (Dirichlet) dofs: the residual stays exactly zero whatever the operator left in h.  The octant form exists only where every Dirichlet condition covers a
     // pair of opposite faces (build_fdm_u), so the eight mirror images of a dof are inert together: one mask byte per thread
-    if (inert && inert[P.node[0] * 3 + c]) continue;
+    if (inert && inert[P.node[0] * NC + c]) continue;
     double w[8]; double s2 = 0;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) w[m] = h[P.node[m] * 3 + c];
+    for (int m = 0; m < 8; ++m) w[m] = h[P.node[m] * NC + c];
     bfly_fwd(w, P.centre);
 #pragma unroll
     for (int o = 0; o < 8; ++o) if (o < D.no) { const int64_t at = (int64_t)(c * D.no + o) * D.co + idx; const double gv = fma(alpha, w[o], g[at]); g[at] = gv; s2 = fma(gv, gv, s2); }
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctDims D, PcgScalars 
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
 }
 // x += alpha d, then d = beta d - H' z unless the solve just finished (k_pcg_update_d_fused with the explicit z in octant form)
-__global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars *sc, int parity, int it, double *__restrict__ x, double *__restrict__ d, const double *__restrict__ z, int64_t n_u, const double *partials_in, const double *red) {
+template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars *sc, int parity, int it, double *__restrict__ x, double *__restrict__ d, const double *__restrict__ z, int64_t n_u, const double *partials_in, const double *red) {
   __shared__ double sh[5];
   if (sc->done) return;
   const double gg = red ? red[0] : sum_partials(partials_in, sh), gz = red ? red[1] : sum_partials(partials_in + kMaxPartials, sh);
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars 
     bfly_bwd(w, P.centre);
 #pragma unroll
     for (int m = 0; m < 8; ++m) if (P.live[m]) {
-      const int64_t dof = P.node[m] * 3 + c;
+      const int64_t dof = P.node[m] * NC + c;
       const double dv = d[dof], xv = x[dof];
       x[dof] = fma(alpha, dv, xv); d[dof] = fma(beta, dv, -w[m]);
     }
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(kBlock) k_fdmo_dot_owned(OctDims D, const doub
   if (gate && (gate->done | gate->finishing)) return;
   // every block of a, b is [plane][position]: the owned planes are its leading part (row pads are zeros in both)
   const int64_t per = (int64_t)D.own_z * D.hxp * D.hy;          // (hxp even: pairs)
-  const int nblk = 3 * D.no, share = gridDim.x / nblk, blk = blockIdx.x / max(share, 1), sub = blockIdx.x - blk * share;   // workgroups per block of the arrays; the remainder idles
+  const int nblk = D.nc * D.no, share = gridDim.x / nblk, blk = blockIdx.x / max(share, 1), sub = blockIdx.x - blk * share;   // workgroups per block of the arrays; the remainder idles
   double acc = 0;
   if (share > 0 && blk < nblk) {
     const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(a + blk * D.co), *__restrict__ b2 = reinterpret_cast<const double2 *>(b + blk * D.co);
@@ -465,6 +465,88 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   }
 }
 
+// ---- planar (2D) form: the blocks are whole (component, quadrant) planes of up to ~350 x 350 entries - too large for one workgroup's LDS, so each of the four
+//      1D transforms is a batched tiled GEMM of its own: C_b (M x N) = A_b (M x K) B_b (K x N), 64 x 64 tiles, 16-deep LDS stages (double buffered), 4 waves x (2 x 2) MFMA tiles.
+//      An operand whose unit stride runs along K is staged "m-major" ([64][16 + 2]), one whose unit stride runs along M / N "k-major" ([16][64 + 16]): both give
+//      conflict-free fragment reads (ds_read_b64: 32 lanes per cycle on 32 bank pairs) and contiguous global loads ----
+struct Gemm2D {
+  int M, N, K, nb;
+  int64_t rsA, csA, rsB, csB, rsC;       // element strides (C: unit column stride)
+  int64_t offA[8], offB[8], offC[8];     // per batch entry, relative to the kernel's A / B / C pointers
+  int scale; const double *lamM[8], *lamN[8]; double cM[8], cN[8];   // epilogue: C[m][n] /= cM lamM[m] + cN lamN[n] (inf -> 0)
+  const PcgScalars *gate;
+};
+template <bool KCONTIG> struct GemmLds { static constexpr int LD = KCONTIG ? 18 : 80, SIZE = KCONTIG ? 64 * 18 : 16 * 80; };
+template <bool AK, bool BK>
+__global__ void __launch_bounds__(256) k_fdmo_gemm2d(Gemm2D G, const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C) {
+  typedef GemmLds<AK> LA; typedef GemmLds<BK> LB;
+  __shared__ double As[2][LA::SIZE], Bs[2][LB::SIZE];
+  if (G.gate && (G.gate->done | G.gate->finishing)) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1, j = lane & 15, kq = lane >> 4;
+  const int tiles_n = (G.N + 63) / 64, tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n, b = blockIdx.y;
+  const int m0 = 64 * tm, n0 = 64 * tn;
+  const double *Ab = A + G.offA[b], *Bb = B + G.offB[b];
+  // global -> registers: 4 consecutive elements along the operand's unit-stride direction per thread
+  double ra[4], rb[4];
+  auto gload = [&](int k0) {
+    if (AK) { const int m = m0 + (tid >> 2), k = k0 + 4 * (tid & 3);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ra[u] = (m < G.M && k + u < G.K) ? Ab[(int64_t)m * G.rsA + (int64_t)(k + u) * G.csA] : 0.0; }
+    else { const int k = k0 + (tid >> 4), m = m0 + 4 * (tid & 15);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ra[u] = (k < G.K && m + u < G.M) ? Ab[(int64_t)(m + u) * G.rsA + (int64_t)k * G.csA] : 0.0; }
+    if (BK) { const int n = n0 + (tid >> 2), k = k0 + 4 * (tid & 3);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rb[u] = (n < G.N && k + u < G.K) ? Bb[(int64_t)(k + u) * G.rsB + (int64_t)n * G.csB] : 0.0; }
+    else { const int k = k0 + (tid >> 4), n = n0 + 4 * (tid & 15);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rb[u] = (k < G.K && n + u < G.N) ? Bb[(int64_t)k * G.rsB + (int64_t)(n + u) * G.csB] : 0.0; }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (AK) As[buf][(tid >> 2) * LA::LD + 4 * (tid & 3) + u] = ra[u]; else As[buf][(tid >> 4) * LA::LD + 4 * (tid & 15) + u] = ra[u];
+      if (BK) Bs[buf][(tid >> 2) * LB::LD + 4 * (tid & 3) + u] = rb[u]; else Bs[buf][(tid >> 4) * LB::LD + 4 * (tid & 15) + u] = rb[u];
+    }
+  };
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) acc[a][c] = v4d{0, 0, 0, 0};
+  const int nk = (G.K + 15) / 16;
+  gload(0); lstore(0);
+  __syncthreads();
+  for (int s = 0; s < nk; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nk) gload(16 * (s + 1));
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) { const int m = 32 * wm + 16 * a + j, k = 4 * kk + kq; fa[a] = AK ? As[buf][m * LA::LD + k] : As[buf][k * LA::LD + m]; }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { const int n = 32 * wn + 16 * c + j, k = 4 * kk + kq; fb[c] = BK ? Bs[buf][n * LB::LD + k] : Bs[buf][k * LB::LD + n]; }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[c], acc[a][c], 0, 0, 0);
+    }
+    if (s + 1 < nk) lstore(buf ^ 1);       // (the other buffer: everybody finished reading it before the barrier that ended the previous stage)
+    __syncthreads();
+  }
+  double *Cb = C + G.offC[b];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) {
+    const int col = n0 + 32 * wn + 16 * c + j;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = m0 + 32 * wm + 16 * a + 4 * q + kq;
+      if (row < G.M && col < G.N) {
+        double v = acc[a][c][q];
+        if (G.scale) { const double den = G.cM[b] * G.lamM[b][row] + G.cN[b] * G.lamN[b][col]; v = den < 1e300 ? v / den : 0.0; }
+        Cb[(int64_t)row * G.rsC + col] = v;
+      }
+    }
+  }
+}
+
 template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid((unsigned)n_items), block(64 * (NT < 4 ? NT : 4));
   // (events attached to the dispatch itself: the kernel's own duration, as rocprofv3 reports it)
@@ -495,8 +577,8 @@ void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const
     default: throw Error("fdmo: half lines of more than 80 entries");
   }
 }
-inline int oct_grid(int64_t co) { return (int)std::min<int64_t>((3 * co + kBlock - 1) / kBlock, kMaxPartials); }   // threads = positions x components, as many per thread as the partial slots demand
-OctDims dims_of(const FdmOct &O) { return OctDims{O.n[0], O.n[1], O.n[2], O.h[0], O.h[1], O.h[2], O.hxp, O.co_stride, O.no, O.own_z}; }
+inline int oct_grid(int64_t co, int nc = 3) { return (int)std::min<int64_t>((nc * co + kBlock - 1) / kBlock, kMaxPartials); }   // threads = positions x components, as many per thread as the partial slots demand
+OctDims dims_of(const FdmOct &O) { return OctDims{O.n[0], O.n[1], O.n[2], O.h[0], O.h[1], O.h[2], O.hxp, O.co_stride, O.no, O.own_z, O.nc}; }
 SlabGeo geo_of(const FdmOct &O) { const auto &S = O.slab; return SlabGeo{S.cw, S.nchunk, S.cps, S.nb * S.nchunk, S.rank, S.my_chunks, S.hzg, S.ng, S.np, S.scols, (int64_t)O.hxp * O.h[1], O.co_stride}; }
 
 }  // namespace
@@ -671,7 +753,7 @@ void fdmo_slab_scatter_pack(hipStream_t s, const FdmOct &O, const PcgScalars *ga
   if (S.my_chunks > 0) hipLaunchKernelGGL(k_fdmo_slab_scatter_pack, copy_grid((int64_t)S.rows_back * S.my_chunks * S.cw), 256, 0, s, G, S.rows_back, S.row_out.p, S.row_kz.p, S.tz.p, S.buf.p, gate);
 }
 void fdmo_dot_owned(hipStream_t s, const FdmOct &O, const double *a, const double *b, double *partials, const PcgScalars *gate) {
-  hipLaunchKernelGGL(k_fdmo_dot_owned, std::max(oct_grid(O.co_stride), 3 * O.no), kBlock, 0, s, dims_of(O), a, b, partials, gate);   // (at least one workgroup per block of the arrays)
+  hipLaunchKernelGGL(k_fdmo_dot_owned, std::max(oct_grid(O.co_stride, O.nc), O.nc * O.no), kBlock, 0, s, dims_of(O), a, b, partials, gate);   // (at least one workgroup per block of the arrays)
 }
 
 // ---- the same three sweeps for a SCALAR Q1 system of the box (pressure Jacobian a M + kappa K, projection mass matrix): one "component", no parity octants, the
@@ -757,19 +839,78 @@ void fdmo_scalar_slab_pass(hipStream_t s, FdmOct &O, int pass, double a, double 
   launch_pass_nt(s, nt, P, P.nblk, in, out);
 }
 
-void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v, double *q) { hipLaunchKernelGGL(k_fdmo_from_nodal, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), v, (const uint8_t *)nullptr, q); }
-void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r, double *v) { hipLaunchKernelGGL(k_fdmo_to_nodal, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), r, v); }
-void fdmo_init_residual(hipStream_t s, const FdmOct &O, double *g, const double *Ax, const double *b, const uint8_t *inert) {
-  hipLaunchKernelGGL(k_fdmo_init_residual, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), g, Ax, b, inert);
+#define PORO_OCT_LAUNCH(kernel, O, ...) do { if ((O).nc == 2) hipLaunchKernelGGL(kernel<2>, oct_grid((O).co_stride, 2), kBlock, 0, s, dims_of(O), __VA_ARGS__); \
+                                              else hipLaunchKernelGGL(kernel<3>, oct_grid((O).co_stride, 3), kBlock, 0, s, dims_of(O), __VA_ARGS__); } while (0)
+// ---- planar form, host side: quadrant layout Q[c][2 py + px][ky][kx] (one plane), transforms as row-major h x h matrices F[mode][node] per (component, direction, parity) ----
+bool fdmo_planar_usable(int dim, const int nn[3]) { return dim == 2 && nn[0] >= 2 && nn[1] >= 2 && nn[0] <= 4096 && nn[1] <= 4096; }
+void fdmo_init_planar(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s) {
+  O.nc = 2; O.no = 4; O.planar = true;
+  for (int d = 0; d < 3; ++d) { O.n[d] = d < 2 ? nn[d] : 1; O.h[d] = d < 2 ? (nn[d] + 1) / 2 : 1; for (int c = 0; c < 3; ++c) O.coef[c][d] = coef[c][d]; }
+  O.nt = 0; O.hxp = (O.h[0] + 1) & ~1; O.own_z = 1;
+  O.co_stride = (int64_t)O.hxp * O.h[1]; O.n_oct = 8 * O.co_stride;
+  O.g.alloc(O.n_oct); O.z.alloc(O.n_oct); O.t.alloc(2 * O.n_oct);
+  O.g.zero(s); O.z.zero(s); O.t.zero(s);
 }
-void fdmo_first_direction(hipStream_t s, const FdmOct &O, double *d, const double *g, const double *z, double *partials) {
-  hipLaunchKernelGGL(k_fdmo_first_direction, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), d, g, z, partials);
+bool fdmo_upload_dir_planar(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn) {
+  const int h = (nn + 1) / 2;
+  if (nn != O.n[dir]) throw Error("fdmo_upload_dir_planar: line length mismatch");
+  std::vector<int> grp[2];
+  for (int m = 0; m < nn; ++m) {
+    if (!(lam[m] < 1e300)) continue;
+    double ds = 0, da = 0, nrm = 0;
+    for (int k = 0; k < nn; ++k) { const double a = S[(size_t)k * nn + m], b = S[(size_t)(nn - 1 - k) * nn + m]; ds += (a - b) * (a - b); da += (a + b) * (a + b); nrm += a * a; }
+    if (ds <= 1e-20 * nrm) grp[0].push_back(m); else if (da <= 1e-20 * nrm) grp[1].push_back(m); else return false;
+  }
+  for (int p = 0; p < 2; ++p) {
+    if ((int)grp[p].size() > h) return false;
+    std::vector<double> F((size_t)h * h, 0.0), lp((size_t)h + 16, std::numeric_limits<double>::infinity());
+    const int ng = (int)grp[p].size();
+    for (int m = 0; m < ng; ++m) { for (int k = 0; k < h; ++k) F[(size_t)m * h + k] = S[(size_t)k * nn + grp[p][m]]; lp[m] = lam[grp[p][m]]; }
+    O.h_lam[comp][dir][p] = lp; O.fwd[comp][dir][p].upload(F); O.lam[comp][dir][p].upload(lp);
+  }
+  return true;
 }
+// z = blockdiag(A_cc)^-1 g in quadrant form: T = X Fx^T, U = (Fy T) / (cx lam_x + cy lam_y), V = Fy^T U, Z = V Fx  - four batched GEMMs over the 8 (component, quadrant) planes
+void fdmo_apply_planar(hipStream_t s, const FdmOct &O, const double *g, double *z, const PcgScalars *gate) {
+  const int hx = O.h[0], hy = O.h[1], hxp = O.hxp; const int64_t co = O.co_stride;
+  double *t1 = O.t.p, *t2 = O.t.p + O.n_oct;
+  const double *F0 = O.fwd[0][0][0].p;
+  Gemm2D G{}; G.nb = 8; G.gate = gate; G.rsC = hxp;
+  auto mat = [&](int c, int dir, int p) { return (int64_t)(O.fwd[c][dir][p].p - F0); };
+  for (int b = 0; b < 8; ++b) { G.offC[b] = (int64_t)b * co; }
+  auto launch = [&](bool ak, bool bk, const double *A, const double *B, double *C) {
+    const dim3 grid((unsigned)(((G.M + 63) / 64) * ((G.N + 63) / 64)), 8);
+    if (ak && bk) hipLaunchKernelGGL((k_fdmo_gemm2d<true, true>), grid, 256, 0, s, G, A, B, C);
+    else if (ak) hipLaunchKernelGGL((k_fdmo_gemm2d<true, false>), grid, 256, 0, s, G, A, B, C);
+    else hipLaunchKernelGGL((k_fdmo_gemm2d<false, false>), grid, 256, 0, s, G, A, B, C);
+  };
+  // 1: T[ky][mx] = sum_kx X[ky][kx] Fx[mx][kx]
+  G.M = hy; G.N = hx; G.K = hx; G.rsA = hxp; G.csA = 1; G.rsB = 1; G.csB = hx; G.scale = 0;
+  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.offA[b] = (int64_t)b * co; G.offB[b] = mat(c, 0, q & 1); }
+  launch(true, true, g, F0, t1);
+  // 2: U[my][mx] = sum_ky Fy[my][ky] T[ky][mx], divided by the eigenvalue sums
+  G.M = hy; G.N = hx; G.K = hy; G.rsA = hy; G.csA = 1; G.rsB = hxp; G.csB = 1; G.scale = 1;
+  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.offA[b] = mat(c, 1, q >> 1); G.offB[b] = (int64_t)b * co;
+                                G.lamM[b] = O.lam[c][1][q >> 1].p; G.lamN[b] = O.lam[c][0][q & 1].p; G.cM[b] = O.coef[c][1]; G.cN[b] = O.coef[c][0]; }
+  launch(true, false, F0, t1, t2);
+  // 3: V[ky][mx] = sum_my Fy[my][ky] U[my][mx]
+  G.rsA = 1; G.csA = hy; G.scale = 0;
+  launch(false, false, F0, t2, t1);
+  // 4: Z[ky][kx] = sum_mx V[ky][mx] Fx[mx][kx]
+  G.M = hy; G.N = hx; G.K = hx; G.rsA = hxp; G.csA = 1; G.rsB = hx; G.csB = 1;
+  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.offA[b] = (int64_t)b * co; G.offB[b] = mat(c, 0, q & 1); }
+  launch(true, false, t1, F0, z);
+}
+
+void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v, double *q) { PORO_OCT_LAUNCH(k_fdmo_from_nodal, O, v, (const uint8_t *)nullptr, q); }
+void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r, double *v) { PORO_OCT_LAUNCH(k_fdmo_to_nodal, O, r, v); }
+void fdmo_init_residual(hipStream_t s, const FdmOct &O, double *g, const double *Ax, const double *b, const uint8_t *inert) { PORO_OCT_LAUNCH(k_fdmo_init_residual, O, g, Ax, b, inert); }
+void fdmo_first_direction(hipStream_t s, const FdmOct &O, double *d, const double *g, const double *z, double *partials) { PORO_OCT_LAUNCH(k_fdmo_first_direction, O, d, g, z, partials); }
 void fdmo_update_g(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, double *g, const double *h, const uint8_t *inert, const double *partials_dh, double *partials_out, const double *red) {
-  hipLaunchKernelGGL(k_fdmo_update_g, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), sc, parity, g, h, inert, partials_dh, partials_out, red);
+  PORO_OCT_LAUNCH(k_fdmo_update_g, O, sc, parity, g, h, inert, partials_dh, partials_out, red);
 }
 void fdmo_update_d(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, int it, double *x, double *d, const double *z, const double *partials_in, const double *red) {
-  hipLaunchKernelGGL(k_fdmo_update_d, oct_grid(O.co_stride), kBlock, 0, s, dims_of(O), sc, parity, it, x, d, z, (int64_t)3 * O.n[0] * O.n[1] * O.n[2], partials_in, red);
+  PORO_OCT_LAUNCH(k_fdmo_update_d, O, sc, parity, it, x, d, z, (int64_t)O.nc * O.n[0] * O.n[1] * O.n[2], partials_in, red);
 }
 
 }  // namespace poro
