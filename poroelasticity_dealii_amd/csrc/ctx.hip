@@ -555,13 +555,15 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       // one rank, uniform box (2D or 3D): the fast diagonalisation is the exact inverse of J, so the update is computed directly and its residual checked against
       // the reference's stopping rule (:175) with one poll; info->iterations = 0 marks a directly solved system.  A failed check falls through to CG with that update as start
       static const bool iterative = std::getenv("PORO_PRES_ITERATIVE") != nullptr;
-      if (!iterative && opts->stop_rule == PORO_STOP_RHS && !c->comm.multi() && stencil) {
+      if (!iterative && opts->stop_rule == PORO_STOP_RHS && stencil) {            // (slab partitions too: the distributed fast diagonalisation is the same exact inverse)
         hipStream_t s = c->stream; double *x = vec(c, PORO_VEC_DP); const double *b = vec(c, PORO_VEC_RESIDUAL_P); const double *y = c->wh_p.p;
         const auto t0 = std::chrono::steady_clock::now();
         fdm_precondition_p(c, ja, kk, b, x);
         { Timed tm(c, "apply_p_stencil"); p_stencil_apply(s, c->dim, c->box, ja, jk, x, c->wh_p.p); }
-        la_residual_norms_many(s, 1, &y, &b, c->n_p, c->partials.p);
+        exchange_add(c, c->wh_p.p, c->n_p, c->comm.part.plane_p);
+        la_residual_norms_many(s, 1, &y, &b, owned(c, c->n_p, c->comm.part.plane_p), c->partials.p);
         pcg_scalars_sum(s, c->partials.p, 2, c->red.p);
+        allreduce_sum(c, c->red.p, 2);
         post_and_wait(c, c->red.p, 2);
         const double res = std::sqrt(c->mailbox->vals[0]), bn = std::sqrt(c->mailbox->vals[1]);
         if (res <= std::max(opts->abs_tol, opts->rel_tol * bn)) {
@@ -668,18 +670,19 @@ int poro_proj_solve_many(poro_ctx *c, const int32_t *entries, int32_t n_entries,
     for (int e = 0; e < n_entries; ++e) if (entries[e] < 0 || entries[e] >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
     static const bool iterative = std::getenv("PORO_PROJ_ITERATIVE") != nullptr;
     const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;
-    if (iterative || opts->preconditioner != PORO_PREC_FDM || opts->stop_rule != PORO_STOP_RHS || c->comm.multi() || c->cons_p.n || !stencil || n_entries < 1 || n_entries > 3 || !fdm_p_supported(c)) return 0;
+    if (iterative || opts->preconditioner != PORO_PREC_FDM || opts->stop_rule != PORO_STOP_RHS || c->cons_p.n || !stencil || n_entries < 1 || n_entries > 3 || !fdm_p_supported(c)) return 0;
     build_fdm_p(c);
-    const bool batched = c->fdm_p_fused.built && !c->fdm_p_fused.slab.on;      // 3D, lines of <= 80 vertices: all right-hand sides in one set of launches
+    const bool batched = !c->comm.multi() && c->fdm_p_fused.built && !c->fdm_p_fused.slab.on;      // one rank, 3D, lines of <= 80 vertices: all right-hand sides in one set of launches
     hipStream_t s = c->stream; const double *b[3]; double *x[3]; const double *y[3];
     if (c->proj_y.n < (size_t)3 * c->n_p) c->proj_y.alloc((size_t)3 * c->n_p);
     for (int e = 0; e < n_entries; ++e) { b[e] = vec(c, PORO_VEC_PROJ_RHS0 + entries[e]); x[e] = vec(c, PORO_VEC_STRAIN0 + entries[e]); y[e] = c->proj_y.p + (size_t)e * c->n_p; }
     const auto t0 = std::chrono::steady_clock::now();
     if (batched) { Timed tm(c, "precondition_p_fdm"); fdmo_scalar_apply_many(s, c->fdm_p_fused, 1.0, 0.0, n_entries, b, x); }
     else { const double kk[3] = {0, 0, 0}; for (int e = 0; e < n_entries; ++e) fdm_precondition_p(c, 1.0, kk, b[e], x[e]); }
-    for (int e = 0; e < n_entries; ++e) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(s, c->dim, c->box, 1.0, 0.0, x[e], const_cast<double *>(y[e])); }
-    la_residual_norms_many(s, n_entries, y, b, c->n_p, c->partials.p);
+    for (int e = 0; e < n_entries; ++e) { { Timed tm(c, "apply_p_stencil"); p_stencil_apply(s, c->dim, c->box, 1.0, 0.0, x[e], const_cast<double *>(y[e])); } exchange_add(c, const_cast<double *>(y[e]), c->n_p, c->comm.part.plane_p); }
+    la_residual_norms_many(s, n_entries, y, b, owned(c, c->n_p, c->comm.part.plane_p), c->partials.p);
     pcg_scalars_sum(s, c->partials.p, 2 * n_entries, c->red.p);
+    allreduce_sum(c, c->red.p, 2 * n_entries);
     post_and_wait(c, c->red.p, 2 * n_entries);
     bool all = true;
     for (int e = 0; e < n_entries; ++e) {
