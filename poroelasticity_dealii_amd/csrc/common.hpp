@@ -115,6 +115,7 @@ struct FdmOct {
   struct Slab {
     bool on = false; int n_ranks = 1, rank = 0;
     int ng = 0, hzg = 0;                          // global nodes of a z line / rows of a transposed block (half length with the parity split, ng without)
+    bool zboth = false; DevBuf<int64_t> dst2;      // z stage with both parity parts of a line per workgroup (no transposed array, no scatter kernel): [ng][2] target offsets of every global plane
     int np = 2, nb = 12;                          // parity parts of the z direction (2; scalar Q1 systems: 1 = no butterfly), blocks of the local arrays (3 components x 4 quadrants; scalar: 1)
     int cw = 64, nchunk = 0, cps = 0, chunk0 = 0, my_chunks = 0;   // chunk width (columns), chunks per (component, quadrant) plane, chunks per rank share, this rank's first global chunk and count
     int64_t scols = 0;                            // columns of a share = cps cw

@@ -547,6 +547,155 @@ __global__ void __launch_bounds__(256) k_fdmo_gemm2d(Gemm2D G, const double *__r
   }
 }
 
+// ---- slab form, z stage with BOTH parity parts of a line in one workgroup (NT = 2, 4, 5) --------------------------------------------------------------------------
+// A workgroup takes 8 NL real columns of the rank's share: it loads every gathered plane ONCE, forms the even part e_k = v_k + v_k' into the left half of the LDS
+// block and the odd part o_k = v_k - v_k' into the right half, runs the half-size forward / scale / backward chain on both halves at once (the column tiles of the
+// left half use the even-mode matrices, those of the right half the odd-mode ones: two fragment streams per wave, + one for the shared tile row at NT = 5), and
+// stores v_k = a + b, v_k' = a - b straight into the scattering all-to-all's buffer - every plane to the one or two ranks that hold it (dst table).  Replaces the
+// two-workgroups-per-chunk pass (each parity read every plane pair again) and the separate scatter kernel.
+template <int NT>
+__global__ void __launch_bounds__(64 * (NT < 4 ? NT : 4))
+k_fdmo_zpass_both(OctPass P, const int64_t *__restrict__ dst /* [ng][2]: offsets of a plane's rows in the exchange buffer, -1 = none */, const double *in, double *out) {
+  typedef PassGeom<NT> Gm;
+  constexpr int NW = NT < 4 ? NT : 4; constexpr bool EXTRA = NT > NW; constexpr int XT = NT - 1;
+  constexpr int NL = NW, HT = NL / 2, HC = 16 * HT;            // column tiles of the LDS block (left half: even part, right half: odd part), real columns of a chunk
+  static_assert(NL % 2 == 0, "both-parity z pass: an even number of column tiles");
+  constexpr int LD = Gm::LDB, NACC = NL + (EXTRA ? 1 : 0), NS = EXTRA ? 3 : 2;
+  __shared__ double L[Gm::PADN * Gm::LDB];
+  if (P.gate && (P.gate->done | P.gate->finishing)) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
+  const int G = P.chunk0 + (int)blockIdx.x, cq = G / P.nchunk;
+  if (G >= P.chunk_total) return;
+  const int b = G - cq * P.nchunk, c = cq >> 2, qd = cq & 3;
+  const int R = P.R, C = min(HC, P.pl - b * HC);
+  const int pw = w >= HT ? 1 : 0;                              // parity of the column tile this wave's share of the extra tile row belongs to
+  const int64_t cb = (int64_t)blockIdx.x * HC;                 // first column of the chunk inside the rank's share
+  // ---- gathered planes -> parity parts in LDS ----
+  {
+    constexpr int HP = HC / 2, TOT = Gm::PADN * HP, PER = (TOT + 64 * NW - 1) / (64 * NW);
+    double2 lo[PER], hi[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP);
+      const bool ok = e < TOT && r < R && c2 < C; const int rr = ok ? r : 0, mr = P.ng - 1 - rr;
+      lo[u] = ok ? *reinterpret_cast<const double2 *>(in + P.row_in[rr] + cb + c2) : double2{0.0, 0.0};
+      hi[u] = (ok && mr != rr) ? *reinterpret_cast<const double2 *>(in + P.row_in[mr] + cb + c2) : double2{0.0, 0.0};
+      if (ok && mr == rr) hi[u] = double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * 64 * NW, r = e / HP, c2 = 2 * (e - r * HP);
+      if (e < TOT) {
+        const bool centre = r < R && (P.ng - 1 - r) == r;
+        *reinterpret_cast<double2 *>(&L[r * LD + c2]) = double2{lo[u].x + hi[u].x, lo[u].y + hi[u].y};
+        *reinterpret_cast<double2 *>(&L[r * LD + HC + c2]) = centre ? double2{0.0, 0.0} : double2{lo[u].x - hi[u].x, lo[u].y - hi[u].y};
+      }
+    }
+  }
+  constexpr int CHK = 2, NCH = Gm::KKP / CHK;
+  double tf[2][NS][CHK];
+  const double *__restrict__ T1e = P.T1[c][0] + lane, *__restrict__ T1o = P.T1[c][1] + lane, *__restrict__ T2e = P.T2[c][0] + lane, *__restrict__ T2o = P.T2[c][1] + lane;
+  auto load_chunk = [&](int buf, int step) {
+    const bool first = step < NCH; const int ch = first ? step : step - NCH;
+    const double *__restrict__ Te = first ? T1e : T2e, *__restrict__ To = first ? T1o : T2o;
+#pragma unroll
+    for (int k = 0; k < CHK; ++k) {
+      tf[buf][0][k] = Te[((int64_t)w * Gm::KKP + CHK * ch + k) * 64];
+      tf[buf][1][k] = To[((int64_t)w * Gm::KKP + CHK * ch + k) * 64];
+      if constexpr (EXTRA) tf[buf][2][k] = (pw ? To : Te)[((int64_t)XT * Gm::KKP + CHK * ch + k) * 64];
+    }
+  };
+  v4d acc[NACC];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = v4d{0, 0, 0, 0};
+  };
+  // acc[u] = tile (w, u) = sum_k T_par(u)(rows of tile w, k) data(k, columns of tile u); extra: acc[NL] = tile (XT, w)
+  auto gemm = [&](auto first_step_c, int kk_n) {
+    constexpr int S0 = decltype(first_step_c)::value;
+    const double *La = L + kq * LD + j, *Lw = La + 16 * w;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int buf = (S0 + ch) & 1;
+#pragma unroll
+      for (int k = 0; k < CHK; ++k) {
+        const int kk = CHK * ch + k;
+        if (kk < Gm::KKP - 3 || kk < kk_n) {
+          double d[NL];
+#pragma unroll
+          for (int t = 0; t < NL; ++t) d[t] = La[4 * kk * LD + 16 * t];
+          double dw = 0; if constexpr (EXTRA) dw = Lw[4 * kk * LD];
+#pragma unroll
+          for (int t = 0; t < NL; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][t < HT ? 0 : 1][k], d[t], acc[t], 0, 0, 0);
+          if constexpr (EXTRA) acc[NL] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[buf][2][k], dw, acc[NL], 0, 0, 0);
+        }
+      }
+      if (S0 + ch + 2 < 2 * NCH) load_chunk(buf, S0 + ch + 2);
+    }
+  };
+  __builtin_amdgcn_s_setprio(3);
+  load_chunk(0, 0); load_chunk(1, 1);
+  zero_acc();
+  __builtin_amdgcn_s_setprio(0);
+  __syncthreads();
+  gemm(std::integral_constant<int, 0>{}, P.kk1);
+  __syncthreads();
+  // ---- divided by the eigenvalue sums -> LDS (same layout) ----
+  {
+    const double *bx = P.bxy + (int64_t)(4 * c + qd) * P.pl; const double czc = P.cz[c];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int tr = a < NL ? w : XT, tc = a < NL ? a : w, par = tc >= HT ? 1 : 0;
+      const double *lamz = P.lam_z[c][par];
+      const double bxy = bx[min(b * HC + 16 * (tc - par * HT) + j, P.pl - 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double den = fma(czc, lamz[16 * tr + 4 * q + kq], bxy);
+        double r = __builtin_amdgcn_rcp(den);
+        r = den < 1e300 ? fma(r, fma(-den, r, 1.0), r) : 0.0;
+        L[(16 * tr + 4 * q + kq) * LD + 16 * tc + j] = acc[a][q] * r;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  zero_acc();
+  __syncthreads();
+  gemm(std::integral_constant<int, NCH>{}, P.kk2);
+  // ---- v_k = a + b, v_k' = a - b -> the scattering all-to-all's buffer ----
+  auto put = [&](int row, int col, double a, double bb) {
+    if (row >= R || col >= C) return;
+    const int mr = P.ng - 1 - row;
+    const double vlo = mr == row ? a : a + bb, vhi = a - bb;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { const int64_t d0 = dst[2 * row + t]; if (d0 >= 0) out[d0 + cb + col] = vlo; }
+    if (mr != row) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { const int64_t d1 = dst[2 * mr + t]; if (d1 >= 0) out[d1 + cb + col] = vhi; }
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < HT; ++u) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) put(16 * w + 4 * q + kq, 16 * u + j, acc[u][q], acc[u + HT][q]);
+  }
+  if constexpr (EXTRA) {
+    // the shared tile row: waves 0 .. HT-1 hold the even-mode sums of column tile w, waves HT .. hold the odd-mode sums of column tile w - HT: swap through LDS
+    __syncthreads();                                 // (everybody has finished reading the block)
+    if (pw) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) L[((w - HT) * 4 + q) * 64 + lane] = acc[NL][q];
+    }
+    __syncthreads();
+    if (!pw) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) put(16 * XT + 4 * q + kq, 16 * w + j, acc[NL][q], L[(w * 4 + q) * 64 + lane]);
+    }
+  }
+}
+template <int NT> void launch_zpass_both(hipStream_t s, const OctPass &P, const int64_t *dst, int n_items, const double *in, double *out, hipEvent_t e0, hipEvent_t e1) {
+  hipExtLaunchKernelGGL((k_fdmo_zpass_both<NT>), dim3((unsigned)n_items), dim3(64 * (NT < 4 ? NT : 4)), 0, s, e0, e1, 0, P, dst, in, out);
+}
+
 template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid((unsigned)n_items), block(64 * (NT < 4 ? NT : 4));
   // (events attached to the dispatch itself: the kernel's own duration, as rocprofv3 reports it)
@@ -603,7 +752,9 @@ static void slab_layout(FdmOct &O, int nb, int np, int rank, const std::vector<i
   auto &S = O.slab; const int N = (int)node_layers.size();
   S.nb = nb; S.np = np; S.hzg = np == 2 ? (S.ng + 1) / 2 : S.ng;
   const int64_t pl = (int64_t)O.hxp * O.h[1];
-  S.cw = 16 * std::min(O.nt, 4); S.nchunk = (int)((pl + S.cw - 1) / S.cw);
+  // displacement system with 2, 4 or 5 tiles per half line: both parity parts of a z line in one workgroup (k_fdmo_zpass_both) - a chunk is then HALF a block wide
+  S.zboth = np == 2 && (O.nt == 2 || O.nt == 4 || O.nt == 5) && !std::getenv("PORO_FDMO_SLAB_TWO_PARITY_WORKGROUPS");
+  S.cw = (S.zboth ? 8 : 16) * std::min(O.nt, 4); S.nchunk = (int)((pl + S.cw - 1) / S.cw);
   const int chunk_total = nb * S.nchunk;
   S.cps = (chunk_total + N - 1) / N; S.chunk0 = rank * S.cps; S.my_chunks = std::max(0, std::min(S.cps, chunk_total - S.chunk0)); S.scols = (int64_t)S.cps * S.cw;
   std::vector<int> off(N), own(N), nl(N); int acc = 0; S.max_own = S.max_nl = S.rows_back = 0;
@@ -616,6 +767,9 @@ static void slab_layout(FdmOct &O, int nb, int np, int rank, const std::vector<i
   for (int q = 0; q < N; ++q) for (int k = 0; k < own[q]; ++k) rin[off[q] + k] = S.recv_off + ((int64_t)q * S.max_own + k) * S.scols;
   { int r = 0; for (int q = 0; q < N; ++q) for (int k = 0; k < nl[q]; ++k, ++r) { rout[r] = ((int64_t)q * S.max_nl + k) * S.scols + (q == rank ? S.recv_off : 0); rkz[r] = off[q] + k; } }
   S.row_in.upload(rin); S.row_out.upload(rout); S.row_kz.upload(rkz);
+  { std::vector<int64_t> d2((size_t)2 * S.ng, -1);           // per global plane: where its rows go in the scattering all-to-all's buffer (one rank, or two for a shared plane)
+    for (int r = 0; r < S.rows_back; ++r) { const int kz = rkz[r]; d2[2 * kz + (d2[2 * kz] >= 0 ? 1 : 0)] = rout[r]; }
+    S.dst2.upload(d2); }
   S.buf.alloc((size_t)2 * blk * N); S.tz.alloc((size_t)np * S.cps * S.hzg * S.cw);
   S.buf.zero(s); S.tz.zero(s);
 }
@@ -736,6 +890,15 @@ void fdmo_slab_pass(hipStream_t s, const FdmOct &O, int pass, const double *in, 
     P.mode = 1; P.R = S.hzg; P.C = S.cw; P.nt_r = tiles(S.hzg); P.nt_c = S.cw / 16; P.kk1 = P.kk2 = ksteps(S.hzg); P.nblk = 1; P.blk_stride = (int64_t)S.hzg * S.cw; P.row_stride = S.cw; P.bit1 = P.bit2 = 2;
     P.slab_z = 2; P.chunk0 = S.chunk0; P.chunk_total = 12 * S.nchunk; P.nchunk = S.nchunk; P.row_in = S.row_in.p; P.ng = S.ng;
     for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][2][p].p; P.T2[c][p] = O.bwd[c][2][p].p; }
+    if (S.zboth) {       // both parity parts per workgroup: `in` and `out` are the exchange buffer (gathered planes in, scattered planes out)
+      if (S.my_chunks > 0) switch (nt) {
+        case 2: launch_zpass_both<2>(s, P, S.dst2.p, S.my_chunks, in, out, e0, e1); break;
+        case 4: launch_zpass_both<4>(s, P, S.dst2.p, S.my_chunks, in, out, e0, e1); break;
+        case 5: launch_zpass_both<5>(s, P, S.dst2.p, S.my_chunks, in, out, e0, e1); break;
+        default: throw Error("fdmo: both-parity z pass needs 2, 4 or 5 tiles per half line");
+      }
+      return;
+    }
     if (S.my_chunks > 0) launch_pass_nt(s, nt, P, 2 * S.my_chunks, in, out, e0, e1);
     return;
   }

@@ -22,7 +22,7 @@ def check(rec, its_slack):
     assert rec["rel_diff_u_vs_single_rank"] <= 1e-7 and rec["rel_diff_p_vs_single_rank"] <= 1e-9, rec
 
 
-@pytest.mark.parametrize("world,n,prec", [(3, 8, "block_fdm"), (4, 8, "chebyshev"), (5, 10, "jacobi")])
+@pytest.mark.parametrize("world,n,prec", [(3, 8, "block_fdm"), (4, 8, "chebyshev"), (5, 10, "jacobi"), (2, 24, "block_fdm"), (3, 48, "block_fdm")])   # (24 / 48 cells: 2 / 4 tiles per half line = the both-parity z pass at its other sizes; 72 cells: 5 tiles)
 def test_rank_threads_small(world, n, prec):
     check(rank_threads.rehearse(world, 3, [n, n, n], 2, prec, 2), its_slack=2)
 
