@@ -242,7 +242,7 @@ struct OctPass {
   int hx, pl;               // mode 1: columns of a plane = hx hy; a column's plane offset -> (my, mx)
   const double *T1[3][2], *T2[3][2];                     // [component][parity], MFMA fragment order [tile][4 NT][64]
   const double *lam_z[3][2]; double cz[3]; const double *bxy;   // mode 1: eigenvalues of the line direction; bxy[(4 c + (o & 3)) pl + column] = the other two directions' share
-  int64_t in_off[3], out_off[3]; int use_in_off, use_out_off;   // batched scalar systems (no_shift = 0, up to 3 blocks = right-hand sides in separate vectors): element offsets of every block from `in` / `out`
+  const double *in_blk[3]; double *out_blk[3]; int use_in_off, use_out_off;   // batched scalar systems (no_shift = 0, up to 3 blocks = right-hand sides in separate vectors): every block's own vector instead of `in` / `out` + block * co_stride
   int bxy_cmul;                 // bxy table: blocks per component (4: displacement system; 0: the scalar systems share one table)
   int no_shift;                 // log2 of the blocks per component (3: octants, 2: quadrants of the slab form, 0: scalar system)
   int slab_z /* parity parts of the transposed blocks: 2, or 1 for the scalar systems; 0: not the slab form */, chunk0, chunk_total, nchunk;   // slab form, pass 2: workgroup = (local chunk, z parity) of the transposed array; its global chunk number gives (component, quadrant, chunk of the plane)
@@ -306,7 +306,9 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
     co = blockIdx.x / P.nblk;
     b = blockIdx.x % P.nblk; c = co >> f_no_shift; o = co & ((1 << f_no_shift) - 1); base = (int64_t)co * P.co_stride + (int64_t)b * P.blk_stride;
   }
-  const int64_t base_in = f_use_in ? P.in_off[co] + (int64_t)b * P.blk_stride : base, base_out = f_use_out ? P.out_off[co] + (int64_t)b * P.blk_stride : base;
+  const int64_t base_in = f_use_in ? (int64_t)b * P.blk_stride : base, base_out = f_use_out ? (int64_t)b * P.blk_stride : base;
+  if (f_use_in) in = P.in_blk[co];
+  if (f_use_out) out = P.out_blk[co];
   const bool heavy = CORNER && w == (int)(blockIdx.x & (NW - 1));   // this wave also computes tile (XT, XT)
   const int R = P.R, C = MODE == 1 ? min(P.C, P.pl - b * P.C) : P.C;
   const double *__restrict__ T1 = P.T1[c][(o >> P.bit1) & 1] + lane, *__restrict__ T2 = P.T2[c][(o >> P.bit2) & 1] + lane;
@@ -472,20 +474,20 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
 struct Gemm2D {
   int M, N, K, nb;
   int64_t rsA, csA, rsB, csB, rsC;       // element strides (C: unit column stride)
-  int64_t offA[8], offB[8], offC[8];     // per batch entry, relative to the kernel's A / B / C pointers
+  const double *A[8], *B[8]; double *C[8];   // per batch entry
   int scale; const double *lamM[8], *lamN[8]; double cM[8], cN[8];   // epilogue: C[m][n] /= cM lamM[m] + cN lamN[n] (inf -> 0)
   const PcgScalars *gate;
 };
 template <bool KCONTIG> struct GemmLds { static constexpr int LD = KCONTIG ? 18 : 80, SIZE = KCONTIG ? 64 * 18 : 16 * 80; };
 template <bool AK, bool BK>
-__global__ void __launch_bounds__(256) k_fdmo_gemm2d(Gemm2D G, const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C) {
+__global__ void __launch_bounds__(256) k_fdmo_gemm2d(Gemm2D G) {
   typedef GemmLds<AK> LA; typedef GemmLds<BK> LB;
   __shared__ double As[2][LA::SIZE], Bs[2][LB::SIZE];
   if (G.gate && (G.gate->done | G.gate->finishing)) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1, j = lane & 15, kq = lane >> 4;
   const int tiles_n = (G.N + 63) / 64, tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n, b = blockIdx.y;
   const int m0 = 64 * tm, n0 = 64 * tn;
-  const double *Ab = A + G.offA[b], *Bb = B + G.offB[b];
+  const double *__restrict__ Ab = G.A[b], *__restrict__ Bb = G.B[b];
   // global -> registers: 4 consecutive elements along the operand's unit-stride direction per thread
   double ra[4], rb[4];
   auto gload = [&](int k0) {
@@ -531,7 +533,7 @@ __global__ void __launch_bounds__(256) k_fdmo_gemm2d(Gemm2D G, const double *__r
     if (s + 1 < nk) lstore(buf ^ 1);       // (the other buffer: everybody finished reading it before the barrier that ended the previous stage)
     __syncthreads();
   }
-  double *Cb = C + G.offC[b];
+  double *__restrict__ Cb = G.C[b];
 #pragma unroll
   for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) {
     const int col = n0 + 32 * wn + 16 * c + j;
@@ -955,7 +957,7 @@ void fdmo_scalar_apply_many(hipStream_t s, FdmOct &O, double a, double kappa, in
   auto ksteps = [](int n) { return (n + 3) / 4; };
   OctPass P{};
   P.co_stride = O.co_stride; P.hx = hx; P.pl = hx * hy; P.bxy = table; P.gate = gate; P.vec2 = 0; P.no_shift = 0; P.bxy_cmul = 0;
-  for (int c = 0; c < nb; ++c) { P.cz[c] = kappa; P.lam_z[c][0] = O.lam[0][2][0].p; P.in_off[c] = g[c] - g[0]; P.out_off[c] = z[c] - z[0]; }
+  for (int c = 0; c < nb; ++c) { P.cz[c] = kappa; P.lam_z[c][0] = O.lam[0][2][0].p; P.in_blk[c] = g[c]; P.out_blk[c] = z[c]; }
   P.mode = 0; P.R = hy; P.C = hx; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hx * hy; P.row_stride = hx; P.bit1 = 0; P.bit2 = 1;
   for (int c = 0; c < nb; ++c) { P.T1[c][0] = O.fwd[0][0][0].p; P.T2[c][0] = O.fwd[0][1][0].p; }
   P.use_in_off = 1; P.use_out_off = 0;
@@ -1037,32 +1039,30 @@ bool fdmo_upload_dir_planar(FdmOct &O, int comp, int dir, const std::vector<doub
 void fdmo_apply_planar(hipStream_t s, const FdmOct &O, const double *g, double *z, const PcgScalars *gate) {
   const int hx = O.h[0], hy = O.h[1], hxp = O.hxp; const int64_t co = O.co_stride;
   double *t1 = O.t.p, *t2 = O.t.p + O.n_oct;
-  const double *F0 = O.fwd[0][0][0].p;
   Gemm2D G{}; G.nb = 8; G.gate = gate; G.rsC = hxp;
-  auto mat = [&](int c, int dir, int p) { return (int64_t)(O.fwd[c][dir][p].p - F0); };
-  for (int b = 0; b < 8; ++b) { G.offC[b] = (int64_t)b * co; }
-  auto launch = [&](bool ak, bool bk, const double *A, const double *B, double *C) {
+  auto launch = [&](bool ak, bool bk) {
     const dim3 grid((unsigned)(((G.M + 63) / 64) * ((G.N + 63) / 64)), 8);
-    if (ak && bk) hipLaunchKernelGGL((k_fdmo_gemm2d<true, true>), grid, 256, 0, s, G, A, B, C);
-    else if (ak) hipLaunchKernelGGL((k_fdmo_gemm2d<true, false>), grid, 256, 0, s, G, A, B, C);
-    else hipLaunchKernelGGL((k_fdmo_gemm2d<false, false>), grid, 256, 0, s, G, A, B, C);
+    if (ak && bk) hipLaunchKernelGGL((k_fdmo_gemm2d<true, true>), grid, 256, 0, s, G);
+    else if (ak) hipLaunchKernelGGL((k_fdmo_gemm2d<true, false>), grid, 256, 0, s, G);
+    else hipLaunchKernelGGL((k_fdmo_gemm2d<false, false>), grid, 256, 0, s, G);
   };
   // 1: T[ky][mx] = sum_kx X[ky][kx] Fx[mx][kx]
   G.M = hy; G.N = hx; G.K = hx; G.rsA = hxp; G.csA = 1; G.rsB = 1; G.csB = hx; G.scale = 0;
-  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.offA[b] = (int64_t)b * co; G.offB[b] = mat(c, 0, q & 1); }
-  launch(true, true, g, F0, t1);
+  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.A[b] = g + (int64_t)b * co; G.B[b] = O.fwd[c][0][q & 1].p; G.C[b] = t1 + (int64_t)b * co; }
+  launch(true, true);
   // 2: U[my][mx] = sum_ky Fy[my][ky] T[ky][mx], divided by the eigenvalue sums
   G.M = hy; G.N = hx; G.K = hy; G.rsA = hy; G.csA = 1; G.rsB = hxp; G.csB = 1; G.scale = 1;
-  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.offA[b] = mat(c, 1, q >> 1); G.offB[b] = (int64_t)b * co;
+  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.A[b] = O.fwd[c][1][q >> 1].p; G.B[b] = t1 + (int64_t)b * co; G.C[b] = t2 + (int64_t)b * co;
                                 G.lamM[b] = O.lam[c][1][q >> 1].p; G.lamN[b] = O.lam[c][0][q & 1].p; G.cM[b] = O.coef[c][1]; G.cN[b] = O.coef[c][0]; }
-  launch(true, false, F0, t1, t2);
+  launch(true, false);
   // 3: V[ky][mx] = sum_my Fy[my][ky] U[my][mx]
   G.rsA = 1; G.csA = hy; G.scale = 0;
-  launch(false, false, F0, t2, t1);
+  for (int b = 0; b < 8; ++b) { G.B[b] = t2 + (int64_t)b * co; G.C[b] = t1 + (int64_t)b * co; }
+  launch(false, false);
   // 4: Z[ky][kx] = sum_mx V[ky][mx] Fx[mx][kx]
   G.M = hy; G.N = hx; G.K = hx; G.rsA = hxp; G.csA = 1; G.rsB = hx; G.csB = 1;
-  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.offA[b] = (int64_t)b * co; G.offB[b] = mat(c, 0, q & 1); }
-  launch(true, false, t1, F0, z);
+  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.A[b] = t1 + (int64_t)b * co; G.B[b] = O.fwd[c][0][q & 1].p; G.C[b] = z + (int64_t)b * co; }
+  launch(true, false);
 }
 
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v, double *q) { PORO_OCT_LAUNCH(k_fdmo_from_nodal, O, v, (const uint8_t *)nullptr, q); }
