@@ -98,7 +98,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   // g = A x - b ; d = -P^-1 g ; gh = g.P^-1 g
   apply(x, h, nullptr); ++applies;
   if (oct) fdmo_init_residual(s, *oct, g, h, b, diag.inert); else pcg_init_residual(s, g, h, b, diag.inert, n);
-  la_dot_partials(s, b, b, n_own, part);
+  if (opts->stop_rule != PORO_STOP_REDUCTION) la_dot_partials(s, b, b, n_own, part);     // ||b||^2 only enters the ||b||-relative stopping rule (the slot keeps an older, finite value otherwise)
   if (precond) (void)(*precond)(g, zbuf, nullptr);
   if (oct) fdmo_first_direction(s, *oct, d, g, zbuf, part + kMaxPartials); else pcg_first_direction(s, d, g, diag, prec, n, n_own, part + kMaxPartials);
   pcg_scalars_sum(s, part, 3, red);

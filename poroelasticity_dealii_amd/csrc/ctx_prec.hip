@@ -316,10 +316,10 @@ void fdm_precondition_u_slab(poro_ctx *c, const double *g, double *z, const PcgS
   double *send = S.buf.p, *recv = S.buf.p + S.recv_off;
   fdmo_slab_pass(s, O, 1, g, S.buf.p, gate);                                          // x, y forward on the local planes; the owned planes go straight into the exchange buffer
   alltoall_blocks(c, send, recv, (int64_t)S.max_own * S.scols, true);
-  if (S.zboth) { Timed tp(c, "fdm_u_slab_scatter_pack"); fdmo_slab_pass(s, O, 2, S.buf.p, S.buf.p, gate); }   // whole z lines of this rank's column share, both parity parts per workgroup: gathered planes in, scattered planes out
+  if (S.zboth) { Timed tp(c, "fdm_u_slab_z_stage"); fdmo_slab_pass(s, O, 2, S.buf.p, S.buf.p, gate); }   // whole z lines of this rank's column share, both parity parts per workgroup: gathered planes in, scattered planes out
   else {
     fdmo_slab_pass(s, O, 2, S.buf.p, S.tz.p, gate);                                   // (tile counts without that variant: one parity part per workgroup, then v_k = a + b, v_k' = a - b in a kernel of its own)
-    Timed tp(c, "fdm_u_slab_scatter_pack"); fdmo_slab_scatter_pack(s, O, gate);
+    Timed tp(c, "fdm_u_slab_z_stage"); fdmo_slab_scatter_pack(s, O, gate);
   }
   alltoall_blocks(c, send, recv, (int64_t)S.max_nl * S.scols, true);
   fdmo_slab_pass(s, O, 3, S.buf.p, z, gate);                                          // y, x backward, reading the received planes in place

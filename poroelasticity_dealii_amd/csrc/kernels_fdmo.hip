@@ -772,8 +772,8 @@ static void slab_layout(FdmOct &O, int nb, int np, int rank, const std::vector<i
   { std::vector<int64_t> d2((size_t)2 * S.ng, -1);           // per global plane: where its rows go in the scattering all-to-all's buffer (one rank, or two for a shared plane)
     for (int r = 0; r < S.rows_back; ++r) { const int kz = rkz[r]; d2[2 * kz + (d2[2 * kz] >= 0 ? 1 : 0)] = rout[r]; }
     S.dst2.upload(d2); }
-  S.buf.alloc((size_t)2 * blk * N); S.tz.alloc((size_t)np * S.cps * S.hzg * S.cw);
-  S.buf.zero(s); S.tz.zero(s);
+  S.buf.alloc((size_t)2 * blk * N); S.buf.zero(s);
+  if (!S.zboth) { S.tz.alloc((size_t)np * S.cps * S.hzg * S.cw); S.tz.zero(s); }      // (the both-parity z pass goes from the gathered planes straight to the scattered ones)
 }
 void fdmo_init_slab(FdmOct &O, const int nn[3], const double coef[3][3], int rank, const std::vector<int> &node_layers, bool has_upper, hipStream_t s) {
   auto &S = O.slab; const int N = (int)node_layers.size();

@@ -29,7 +29,7 @@ def box_problem(dim, n, deg, rank=0, n_ranks=1):
     return pk.Problem.box(dim, list(n), [10.0] * dim, deg, bench.material(), bench.BC_3D[:2 * dim], (), rank, n_ranks)
 
 PREC = {"jacobi": pk.PREC_JACOBI, "chebyshev": pk.PREC_CHEBYSHEV, "block_fdm": pk.PREC_FDM}
-FAMILIES = ("apply_u_matrix_free", "apply_u_chebyshev_fused", "precondition_u_fdm", "fdm_u_slab_scatter_pack", "halo_exchange", "allreduce", "alltoall")
+FAMILIES = ("apply_u_matrix_free", "apply_u_chebyshev_fused", "precondition_u_fdm", "fdm_u_slab_z_stage", "halo_exchange", "allreduce", "alltoall")
 
 
 class ThreadComm:
@@ -111,7 +111,7 @@ def rehearse(world, dim, n, deg, prec_name, steps):
     lf = multi[min(1, world - 1)]["families"]          # an interior rank (two neighbours)
     rec["per_cg_iteration_u_on_an_interior_rank"] = {"operator_applications": lf["apply_u_matrix_free"][1] / max(its, 1), "halo_exchanges_all_systems": lf["halo_exchange"][1] / max(its, 1),
                                                       "allreduces_all_systems": lf["allreduce"][1] / max(its, 1), "alltoalls_all_systems": lf["alltoall"][1] / max(its, 1),
-                                                      "block_fdm_applications_in_slab_form": lf["fdm_u_slab_scatter_pack"][1] / max(its, 1),
+                                                      "block_fdm_applications_in_slab_form": lf["fdm_u_slab_z_stage"][1] / max(its, 1),
                                                       "note": "exchange / reduction counts cover ALL solves of the steps (displacement, pressure Newton, 3 projections, residual norms) divided by the displacement CG iterations"}
     u = stitch([m["u"] for m in multi], multi[0]["plane_u"]); p = stitch([m["p"] for m in multi], multi[0]["plane_p"])
     rec["shared_plane_copies_max_abs_diff_u"] = max((float(np.abs(a["u"][-a["plane_u"]:] - b["u"][:a["plane_u"]]).max()) for a, b in zip(multi[:-1], multi[1:])), default=0.0)
