@@ -35,3 +35,11 @@ def test_config4_partition_8_slabs_of_9_layers():
     it = rec["per_cg_iteration_u_on_an_interior_rank"]
     assert it["operator_applications"] <= 1.3 and it["alltoalls_all_systems"] <= 5.0, it   # per iteration: 1 operator application (+ the initial residual), 2 all-to-alls (+ the share of the pressure / projection solves: 16 per step)
     assert it["block_fdm_applications_in_slab_form"] >= 1.0, it                          # the quadrant-form kernels (kernels_fdmo.hip) did the preconditioning, not the nodal fallback
+
+
+def test_nodal_fallback_of_the_distributed_q1_fast_diagonalisation(monkeypatch):
+    """boxes whose Q1 lines are longer than 80 vertices keep the nodal form of the distributed pressure / projection fast diagonalisation (batched window copies around
+    the two all-to-alls); forced here on a small box, together with the two-workgroup z stage of the displacement system"""
+    monkeypatch.setenv("PORO_FDM_P_UNFUSED", "1")
+    monkeypatch.setenv("PORO_FDMO_SLAB_TWO_PARITY_WORKGROUPS", "1")
+    check(rank_threads.rehearse(3, 3, [10, 9, 24], 2, "block_fdm", 2), its_slack=2)
