@@ -166,6 +166,37 @@ template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_update_g(OctD
   store_partial(partials_out, gg);
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
 }
+// the same with TWO neighbouring positions (idx, idx + 1: same row, the pitch is even) per thread: 16-byte accesses on the octant side (twice as long contiguous pieces per
+// component and instruction), the nodal side reads two dofs 8 NC bytes apart
+template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_update_g2(OctDims D, PcgScalars *sc, int parity, double *__restrict__ g, const double *__restrict__ h, const uint8_t *__restrict__ inert, const double *partials_dh, double *partials_out, const double *red) {
+  __shared__ double sh[5];
+  if (sc->done) return;
+  if (sc->finishing) { if (blockIdx.x == 0 && threadIdx.x == 0) sc->done = 1; return; }
+  const double dh = red ? red[0] : sum_partials(partials_dh, sh);
+  const double alpha = sc->gh2[parity] / dh;
+  double gg = 0;
+  for (int64_t t_ = (int64_t)blockIdx.x * kBlock + threadIdx.x; t_ < NC * (D.co / 2); t_ += (int64_t)gridDim.x * kBlock) {
+    const int64_t pr = t_ / NC; const int c = (int)(t_ - NC * pr); const int64_t idx = 2 * pr;
+    const OctPos P0(D, idx), P1(D, idx + 1);
+    double w0[8], w1[8];
+    const bool on0 = P0.valid && !(inert && inert[P0.node[0] * NC + c]), on1 = P1.valid && !(inert && inert[P1.node[0] * NC + c]);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { w0[m] = on0 ? h[P0.node[m] * NC + c] : 0.0; w1[m] = on1 ? h[P1.node[m] * NC + c] : 0.0; }
+    bfly_fwd(w0, P0.centre); bfly_fwd(w1, P1.centre);
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) if (o < D.no) {
+      double2 *gp = reinterpret_cast<double2 *>(g + (int64_t)(c * D.no + o) * D.co + idx);
+      double2 gv = *gp;
+      gv.x = fma(alpha, w0[o], gv.x); gv.y = fma(alpha, w1[o], gv.y);       // (inert dofs and row pads: w = 0, g stays what it is - zero)
+      *gp = gv; s0 = fma(gv.x, gv.x, s0); s1 = fma(gv.y, gv.y, s1);
+    }
+    if (P0.own) gg = fma(P0.weight, s0, fma(P1.weight, s1, gg));
+  }
+  gg = block_sum(gg, sh);
+  store_partial(partials_out, gg);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->dh = dh; sc->alpha = alpha; }
+}
 // x += alpha d, then d = beta d - H' z unless the solve just finished (k_pcg_update_d_fused with the explicit z in octant form)
 template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctDims D, PcgScalars *sc, int parity, int it, double *__restrict__ x, double *__restrict__ d, const double *__restrict__ z, int64_t n_u, const double *partials_in, const double *red) {
   __shared__ double sh[5];
@@ -180,7 +211,7 @@ template <int NC> __global__ void __launch_bounds__(kBlock) k_fdmo_update_d(OctD
     return;
   }
   const double beta = gz / gh_old;
-  PORO_OCT_LOOP(D) {
+  PORO_OCT_LOOP(D) {          // (two positions per thread, as in k_fdmo_update_g2, were measured here too: 72 instead of 59 us - the paired read-modify-writes of the nodal vectors cost more than the 16-byte octant reads save)
     PORO_OCT_DECODE(D)
     double w[8];
 #pragma unroll
@@ -1070,7 +1101,9 @@ void fdmo_to_nodal(hipStream_t s, const FdmOct &O, const double *r, double *v) {
 void fdmo_init_residual(hipStream_t s, const FdmOct &O, double *g, const double *Ax, const double *b, const uint8_t *inert) { PORO_OCT_LAUNCH(k_fdmo_init_residual, O, g, Ax, b, inert); }
 void fdmo_first_direction(hipStream_t s, const FdmOct &O, double *d, const double *g, const double *z, double *partials) { PORO_OCT_LAUNCH(k_fdmo_first_direction, O, d, g, z, partials); }
 void fdmo_update_g(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, double *g, const double *h, const uint8_t *inert, const double *partials_dh, double *partials_out, const double *red) {
-  PORO_OCT_LAUNCH(k_fdmo_update_g, O, sc, parity, g, h, inert, partials_dh, partials_out, red);
+  static const bool single = std::getenv("PORO_FDMO_UPDATE_G_SINGLE") != nullptr;
+  if (single) PORO_OCT_LAUNCH(k_fdmo_update_g, O, sc, parity, g, h, inert, partials_dh, partials_out, red);
+  else PORO_OCT_LAUNCH(k_fdmo_update_g2, O, sc, parity, g, h, inert, partials_dh, partials_out, red);
 }
 void fdmo_update_d(hipStream_t s, const FdmOct &O, PcgScalars *sc, int parity, int it, double *x, double *d, const double *z, const double *partials_in, const double *red) {
   PORO_OCT_LAUNCH(k_fdmo_update_d, O, sc, parity, it, x, d, z, (int64_t)O.nc * O.n[0] * O.n[1] * O.n[2], partials_in, red);
