@@ -98,7 +98,7 @@ struct FdmU { int dim = 0; int nn[3] = {1, 1, 1}; double coef[3][3] = {}; FdmuDi
 // direction.  Each of the 24 (component, octant) blocks is then an independent half-size 3D transform, done in three passes (x y fused per plane, z
 // forward + eigenvalue scaling + z backward, y x fused per plane); the butterflies ride in the CG update kernels, which touch every entry anyway.
 struct FdmOct {
-  bool built = false; int nt = 0;                 // 16-wide MFMA tiles per half line (max over the directions), 1..5
+  bool built = false; int nt = 0;                 // 16-wide MFMA tiles per half line (max over the directions), 1..8
   int n[3] = {1, 1, 1}, h[3] = {1, 1, 1}; int hxp = 2;   // hxp: row pitch = h[0] rounded up to even (16-byte aligned rows; the pad entry is zero and stays zero)
   int64_t co_stride = 0, n_oct = 0;               // entries per (component, octant) = hxp h[1] h[2]; 24 co_stride
   double coef[3][3] = {};
@@ -218,7 +218,7 @@ struct poro_ctx {
   double cheb_ratio_default = 0;   // default interval ratio of the Chebyshev preconditioner, from the GLOBAL mesh size (0 = not yet computed)
   poro::DevBuf<double> cheb_z, cheb_t;
   poro::FdmOct fdm_oct;
-  poro::FdmOct fdm_p_fused;          // the scalar Q1 systems through the same transform kernel (3D boxes, one rank, lines of <= 80 nodes)
+  poro::FdmOct fdm_p_fused;          // the scalar Q1 systems through the same transform kernel (3D boxes, lines of <= 128 vertices)
   // two-level preconditioner (poro_desc.coarse): the underlying uniform box as a context of its own (same device and stream) + the node-wise interpolation P and its transpose
   struct TwoLevel { poro_ctx *box = nullptr; int64_t n_fine = 0, n_coarse = 0; poro::DevBuf<int64_t> p_ptr, pt_ptr; poro::DevBuf<int32_t> p_col, pt_col; poro::DevBuf<double> p_w, pt_w; } two_level;
   bool borrowed_stream = false;     // (the box context of a two-level preconditioner runs on its parent's stream)
@@ -361,7 +361,7 @@ void fdmu_window(hipStream_t s, double *dst, const double *src, bool to_block, i
                  int64_t grid_stride, int64_t grid_planes, int64_t grid_col0, int64_t grid_plane0);
 void fdmu_lines(hipStream_t s, const FdmU &F, const FdmuDir *last_dir, int64_t C, int64_t col0, int64_t ncol_valid, void *in, void *out);
 // ---- kernels_fdmo.hip: octant form (see FdmOct) --------------------------------------------------
-bool fdmo_usable(int dim, const int nn[3]);          // 3D, half lines of at most 80 entries
+bool fdmo_usable(int dim, const int nn[3]);          // 3D, half lines of at most 128 entries (8 MFMA tiles)
 void fdmo_init(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s);   // sizes + buffers
 // slab-partitioned form: nn = LOCAL nodes; layers[q] = node planes rank q holds minus one (its cell layers x degree); the last direction's matrices are uploaded for the GLOBAL line
 void fdmo_init_slab(FdmOct &O, const int nn[3], const double coef[3][3], int rank, const std::vector<int> &node_layers, bool has_upper, hipStream_t s);

@@ -672,7 +672,7 @@ int poro_proj_solve_many(poro_ctx *c, const int32_t *entries, int32_t n_entries,
     const bool stencil = c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled;
     if (iterative || opts->preconditioner != PORO_PREC_FDM || opts->stop_rule != PORO_STOP_RHS || c->cons_p.n || !stencil || n_entries < 1 || n_entries > 3 || !fdm_p_supported(c)) return 0;
     build_fdm_p(c);
-    const bool batched = !c->comm.multi() && c->fdm_p_fused.built && !c->fdm_p_fused.slab.on;      // one rank, 3D, lines of <= 80 vertices: all right-hand sides in one set of launches
+    const bool batched = !c->comm.multi() && c->fdm_p_fused.built && !c->fdm_p_fused.slab.on;      // one rank, 3D, lines of <= 128 vertices: all right-hand sides in one set of launches
     hipStream_t s = c->stream; const double *b[3]; double *x[3]; const double *y[3];
     if (c->proj_y.n < (size_t)3 * c->n_p) c->proj_y.alloc((size_t)3 * c->n_p);
     for (int e = 0; e < n_entries; ++e) { b[e] = vec(c, PORO_VEC_PROJ_RHS0 + entries[e]); x[e] = vec(c, PORO_VEC_STRAIN0 + entries[e]); y[e] = c->proj_y.p + (size_t)e * c->n_p; }

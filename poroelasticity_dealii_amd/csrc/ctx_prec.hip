@@ -268,7 +268,7 @@ void build_fdm_u(poro_ctx *c) {
     F.sendbuf.alloc(blk * N); F.recvbuf.alloc(blk * N); F.tz1.alloc((size_t)dim * F.ng * F.C); F.tz2.alloc((size_t)dim * F.ng * F.C);
     F.sendbuf.zero(c->stream); F.recvbuf.zero(c->stream); F.tz1.zero(c->stream); F.tz2.zero(c->stream);
   }
-  // octant form (kernels_fdmo.hip): one rank, 3D, every direction mirror-symmetric for every component, half lines of at most 80 entries
+  // octant form (kernels_fdmo.hip): one rank, 3D, every direction mirror-symmetric for every component, half lines of at most 128 entries
   // slab partitions: the quadrant form (x, y split locally; the z butterfly next to the all-to-all) under the same conditions on the GLOBAL line
   bool oct_ok = !F.single && !std::getenv("PORO_FDMU_NO_OCT");
   bool planar = false;     // 2D, one rank: the quadrant form with a single plane, transforms as batched GEMMs (lines of any length)

@@ -26,6 +26,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <limits>
+#include <mutex>
+#include <set>
 #include <type_traits>
 
 namespace poro {
@@ -287,6 +289,8 @@ struct OctPass {
   unsigned long long *stamps;   // diagnostic (PORO_FDMO_STAMPS): per block 8 words: 100 MHz time at start / block in LDS / GEMM 1 done / intermediate in LDS / GEMM 2 done / stored, HW_ID, XCC_ID
 };
 
+constexpr int kFdmoMaxTiles = 8;                                  // 16-wide tiles per half line the transform kernel is instantiated for (half lines of <= 128 entries)
+template <int NT> constexpr int pass_waves() { return NT == 5 ? 4 : NT; }   // waves of a workgroup: one per tile row / column, except NT = 5 (four waves share 25 tiles)
 template <int NT> struct PassGeom {
   static constexpr int PADN = 16 * NT, KKP = 4 * NT;
   static constexpr int LDA = PADN + 2;                       // data as the A operand: lane (i, kq) reads [16 t + i][4 kk + kq]; LD = 2 * odd (mod 32) keeps a 32-lane group on 32 bank pairs
@@ -306,7 +310,7 @@ template <int NT> struct PassGeom {
 // VAR = 1: the quadrant form of the displacement system on slabs (pass 1 stores into / pass 3 loads from the exchange buffer, pass 2 forms the parity parts on load), likewise;
 // VAR = 2: everything else by run-time switches (scalar systems, batched right-hand sides)
 template <int NT, int MODE, int VAR>
-__global__ void __launch_bounds__(64 * (NT < 4 ? NT : 4))
+__global__ void __launch_bounds__(64 * pass_waves<NT>())
 k_fdmo_pass(OctPass P, const double *in, double *out) {
   // (the kernel argument stays in the kernarg segment - a modified copy would live in scratch because of its dynamically indexed members)
   constexpr bool GENERAL = VAR == 2, SLAB = VAR == 1;
@@ -314,7 +318,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
             f_use_in = GENERAL ? P.use_in_off : 0, f_use_out = GENERAL ? P.use_out_off : 0, f_no_shift = GENERAL ? P.no_shift : (SLAB ? 2 : 3), f_bxy_cmul = GENERAL ? P.bxy_cmul : 4;
   const int64_t *const f_row_in = (GENERAL || (SLAB && MODE == 1)) ? P.row_in : nullptr;
   typedef PassGeom<NT> Gm;
-  constexpr int NW = NT < 4 ? NT : 4;                        // waves
+  constexpr int NW = pass_waves<NT>();                       // waves
   constexpr bool EXTRA = NT > NW;                            // NT == 5: the fifth tile row / column is shared out
   constexpr int XT = NT - 1;                                 // index of that tile row / column
   constexpr int NL = (MODE == 1 && EXTRA) ? NW : NT;         // tiles a wave loops over beside its own (pass 2: column tiles of a chunk)
@@ -324,7 +328,7 @@ k_fdmo_pass(OctPass P, const double *in, double *out) {
   constexpr int LD1 = kColsFirst ? Gm::LDA : Gm::LDB, LD2 = kColsSecond ? Gm::LDA : Gm::LDB;
   constexpr int NS = EXTRA ? 2 : 1;                          // fragment streams per wave: its own tile row of T (and the shared one)
   constexpr int PADC = 16 * NL;                              // padded block columns
-  __shared__ double L[Gm::PADN * Gm::LDMAX];
+  extern __shared__ double L[];                              // PADN x LDMAX doubles (dynamic: more than 64 KB from NT = 6 on)
   if (P.gate && (P.gate->done | P.gate->finishing)) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
@@ -729,24 +733,27 @@ template <int NT> void launch_zpass_both(hipStream_t s, const OctPass &P, const 
   hipExtLaunchKernelGGL((k_fdmo_zpass_both<NT>), dim3((unsigned)n_items), dim3(64 * (NT < 4 ? NT : 4)), 0, s, e0, e1, 0, P, dst, in, out);
 }
 
+// one instantiation: dynamic LDS (more than 64 KB from NT = 6 on: opted in once per device), events attached to the dispatch itself (the kernel's own duration, as rocprofv3 reports it)
+template <int NT, int MODE, int VAR> void launch_one(hipStream_t s, int n_items, const OctPass &P, const double *in, double *out, hipEvent_t e0, hipEvent_t e1) {
+  constexpr unsigned lds = (unsigned)(PassGeom<NT>::PADN * PassGeom<NT>::LDMAX * sizeof(double));
+  auto kernel = k_fdmo_pass<NT, MODE, VAR>;
+  if (lds > 64 * 1024) {
+    static std::mutex mu; static std::set<int> done; int dev = 0; PORO_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.count(dev)) { PORO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done.insert(dev); }
+  }
+  hipExtLaunchKernelGGL(kernel, dim3((unsigned)n_items), dim3(64 * pass_waves<NT>()), lds, s, e0, e1, 0, P, in, out);
+}
 template <int NT> void launch_pass(hipStream_t s, const OctPass &P, int n_items, const double *in, double *out, hipEvent_t e0, hipEvent_t e1) {
-  const dim3 grid((unsigned)n_items), block(64 * (NT < 4 ? NT : 4));
-  // (events attached to the dispatch itself: the kernel's own duration, as rocprofv3 reports it)
   const bool plain = P.vec2 == 1 && !P.use_in_off && !P.use_out_off && P.bxy_cmul == 4;
   const bool oct = plain && P.slab_z == 0 && P.slab_io == 0 && !P.row_in && P.no_shift == 3;
   const bool slab_u = plain && P.no_shift == 2 && ((P.mode == 0 && P.slab_io == 1 && !P.slab_z) || (P.mode == 1 && P.slab_z == 2 && P.row_in && !P.slab_io) || (P.mode == 2 && P.slab_io == 2 && !P.slab_z));
   if (oct) {
-    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, 0>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, 0>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, 0>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    if (P.mode == 0) launch_one<NT, 0, 0>(s, n_items, P, in, out, e0, e1); else if (P.mode == 1) launch_one<NT, 1, 0>(s, n_items, P, in, out, e0, e1); else launch_one<NT, 2, 0>(s, n_items, P, in, out, e0, e1);
   } else if (slab_u) {
-    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, 1>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, 1>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, 1>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    if (P.mode == 0) launch_one<NT, 0, 1>(s, n_items, P, in, out, e0, e1); else if (P.mode == 1) launch_one<NT, 1, 1>(s, n_items, P, in, out, e0, e1); else launch_one<NT, 2, 1>(s, n_items, P, in, out, e0, e1);
   } else {
-    if (P.mode == 0) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 0, 2>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else if (P.mode == 1) hipExtLaunchKernelGGL((k_fdmo_pass<NT, 1, 2>), grid, block, 0, s, e0, e1, 0, P, in, out);
-    else hipExtLaunchKernelGGL((k_fdmo_pass<NT, 2, 2>), grid, block, 0, s, e0, e1, 0, P, in, out);
+    if (P.mode == 0) launch_one<NT, 0, 2>(s, n_items, P, in, out, e0, e1); else if (P.mode == 1) launch_one<NT, 1, 2>(s, n_items, P, in, out, e0, e1); else launch_one<NT, 2, 2>(s, n_items, P, in, out, e0, e1);
   }
 }
 void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const double *in, double *out, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
@@ -756,9 +763,14 @@ void launch_pass_nt(hipStream_t s, int nt, const OctPass &P, int n_blocks, const
     case 3: launch_pass<3>(s, P, n_blocks, in, out, e0, e1); break;
     case 4: launch_pass<4>(s, P, n_blocks, in, out, e0, e1); break;
     case 5: launch_pass<5>(s, P, n_blocks, in, out, e0, e1); break;
-    default: throw Error("fdmo: half lines of more than 80 entries");
+    case 6: launch_pass<6>(s, P, n_blocks, in, out, e0, e1); break;
+    case 7: launch_pass<7>(s, P, n_blocks, in, out, e0, e1); break;
+    case 8: launch_pass<8>(s, P, n_blocks, in, out, e0, e1); break;
+    default: throw Error("fdmo: half lines of more than 128 entries");
   }
 }
+// columns of a pass-2 chunk: one 16-wide tile per wave (NT = 5: four waves)
+inline int pass2_chunk(int nt) { return nt == 5 ? 64 : 16 * nt; }
 inline int oct_grid(int64_t co, int nc = 3) { return (int)std::min<int64_t>((nc * co + kBlock - 1) / kBlock, kMaxPartials); }   // threads = positions x components, as many per thread as the partial slots demand
 OctDims dims_of(const FdmOct &O) { return OctDims{O.n[0], O.n[1], O.n[2], O.h[0], O.h[1], O.h[2], O.hxp, O.co_stride, O.no, O.own_z, O.nc}; }
 SlabGeo geo_of(const FdmOct &O) { const auto &S = O.slab; return SlabGeo{S.cw, S.nchunk, S.cps, S.nb * S.nchunk, S.rank, S.my_chunks, S.hzg, S.ng, S.np, S.scols, (int64_t)O.hxp * O.h[1], O.co_stride}; }
@@ -767,7 +779,7 @@ SlabGeo geo_of(const FdmOct &O) { const auto &S = O.slab; return SlabGeo{S.cw, S
 
 bool fdmo_usable(int dim, const int nn[3]) {
   if (dim != 3) return false;
-  for (int d = 0; d < 3; ++d) if ((nn[d] + 1) / 2 > 80 || nn[d] < 2) return false;
+  for (int d = 0; d < 3; ++d) if ((nn[d] + 1) / 2 > 16 * kFdmoMaxTiles || nn[d] < 2) return false;
   return true;
 }
 
@@ -787,7 +799,7 @@ static void slab_layout(FdmOct &O, int nb, int np, int rank, const std::vector<i
   const int64_t pl = (int64_t)O.hxp * O.h[1];
   // displacement system with 2, 4 or 5 tiles per half line: both parity parts of a z line in one workgroup (k_fdmo_zpass_both) - a chunk is then HALF a block wide
   S.zboth = np == 2 && (O.nt == 2 || O.nt == 4 || O.nt == 5) && !std::getenv("PORO_FDMO_SLAB_TWO_PARITY_WORKGROUPS");
-  S.cw = (S.zboth ? 8 : 16) * std::min(O.nt, 4); S.nchunk = (int)((pl + S.cw - 1) / S.cw);
+  S.cw = S.zboth ? pass2_chunk(O.nt) / 2 : pass2_chunk(O.nt); S.nchunk = (int)((pl + S.cw - 1) / S.cw);
   const int chunk_total = nb * S.nchunk;
   S.cps = (chunk_total + N - 1) / N; S.chunk0 = rank * S.cps; S.my_chunks = std::max(0, std::min(S.cps, chunk_total - S.chunk0)); S.scols = (int64_t)S.cps * S.cw;
   std::vector<int> off(N), own(N), nl(N); int acc = 0; S.max_own = S.max_nl = S.rows_back = 0;
@@ -884,11 +896,11 @@ void fdmo_apply(hipStream_t s, const FdmOct &O, const double *g_oct, double *z_o
   // pass 1: per z-plane, X[ky][kx] -> Fy (X Fx^T)
   P.mode = 0; P.R = hy; P.C = hxp; P.nt_r = tiles(hy); P.nt_c = tiles(hx); P.kk1 = ksteps(hx); P.kk2 = ksteps(hy); P.nblk = hz; P.blk_stride = (int64_t)hxp * hy; P.row_stride = hxp; P.bit1 = 0; P.bit2 = 1;
   for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][0][p].p; P.T2[c][p] = O.fwd[c][1][p].p; }
-  if (stamping) { stamps.alloc((size_t)8 * 24 * (O.h[2] + (hxp * hy + 16 * std::min(nt, 4) - 1) / (16 * std::min(nt, 4)) + O.h[2])); stamps.zero(s); }
+  if (stamping) { stamps.alloc((size_t)8 * 24 * (O.h[2] + (hxp * hy + pass2_chunk(nt) - 1) / pass2_chunk(nt) + O.h[2])); stamps.zero(s); }
   P.stamps = stamping ? stamps.p : nullptr; stamp_off.push_back({24 * P.nblk, 0});
   launch_pass_nt(s, nt, P, 24 * P.nblk, g_oct, scratch, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
   // pass 2: per chunk of 16 NT columns of a (component, octant) block, X[kz][col] -> Bz scale (Fz X), in place
-  const int cw = 16 * std::min(nt, 4);            // chunk width of pass 2: 5 x 4 tiles for the four waves of an NT = 5 workgroup
+  const int cw = pass2_chunk(nt);                 // chunk width of pass 2: one column tile per wave (NT = 5: 5 x 4 tiles for the four waves of the workgroup)
   P.mode = 1; P.R = hz; P.C = cw; P.nt_r = tiles(hz); P.nt_c = cw / 16; P.kk1 = ksteps(hz); P.kk2 = ksteps(hz); P.nblk = (hxp * hy + cw - 1) / cw; P.blk_stride = cw; P.row_stride = (int64_t)hxp * hy; P.bit1 = 2; P.bit2 = 2;
   for (int c = 0; c < 3; ++c) for (int p = 0; p < 2; ++p) { P.T1[c][p] = O.fwd[c][2][p].p; P.T2[c][p] = O.bwd[c][2][p].p; }
   if (stamping) P.stamps = stamps.p + 8 * (int64_t)(24 * hz); stamp_off.push_back({24 * P.nblk, 8 * (int64_t)(24 * hz)});
@@ -954,7 +966,7 @@ void fdmo_dot_owned(hipStream_t s, const FdmOct &O, const double *a, const doubl
 
 // ---- the same three sweeps for a SCALAR Q1 system of the box (pressure Jacobian a M + kappa K, projection mass matrix): one "component", no parity octants, the
 // vectors keep their nodal layout [z][y][x] (full-length lines, odd pitch: 8-byte block loads).  Replaces six single-direction launches of kernels_fdm.hip.
-bool fdmo_scalar_usable(int dim, const int nn[3]) { if (dim != 3) return false; for (int d = 0; d < 3; ++d) if (nn[d] > 80 || nn[d] < 2) return false; return true; }
+bool fdmo_scalar_usable(int dim, const int nn[3]) { if (dim != 3) return false; for (int d = 0; d < 3; ++d) if (nn[d] > 16 * kFdmoMaxTiles || nn[d] < 2) return false; return true; }
 void fdmo_scalar_init(FdmOct &O, const int nn[3], hipStream_t s) {
   int hmax = 1;
   for (int d = 0; d < 3; ++d) { O.n[d] = nn[d]; O.h[d] = nn[d]; hmax = std::max(hmax, nn[d]); }
@@ -993,7 +1005,7 @@ void fdmo_scalar_apply_many(hipStream_t s, FdmOct &O, double a, double kappa, in
   for (int c = 0; c < nb; ++c) { P.T1[c][0] = O.fwd[0][0][0].p; P.T2[c][0] = O.fwd[0][1][0].p; }
   P.use_in_off = 1; P.use_out_off = 0;
   launch_pass_nt(s, nt, P, nb * P.nblk, g[0], O.t.p);
-  const int cw = 16 * std::min(nt, 4);
+  const int cw = pass2_chunk(nt);
   P.mode = 1; P.R = hz; P.C = cw; P.nt_r = tiles(hz); P.nt_c = cw / 16; P.kk1 = ksteps(hz); P.kk2 = ksteps(hz); P.nblk = (hx * hy + cw - 1) / cw; P.blk_stride = cw; P.row_stride = (int64_t)hx * hy; P.bit1 = 2; P.bit2 = 2;
   for (int c = 0; c < nb; ++c) { P.T1[c][0] = O.fwd[0][2][0].p; P.T2[c][0] = O.bwd[0][2][0].p; }
   P.use_in_off = 0;
