@@ -123,3 +123,33 @@ def test_condensed_solve_equals_direct_elimination(dim, n, deg, lo, hi):
         assert np.linalg.norm(u - x) <= 1e-9 * np.linalg.norm(x)
     finally:
         O.close(); Oraw.close(); P.close()
+
+
+@pytest.mark.parametrize("dim,n,deg,lo,hi", MESHES, ids=str)
+def test_coarse_space_of_a_refined_box_interpolates_polynomials(dim, n, deg, lo, hi):
+    """poro_desc.coarse (the two-level preconditioner's coarse space): every displacement node of the refined mesh carries the underlying uniform box's shape functions
+    evaluated at its position - rows sum to one, the coordinate functions are reproduced exactly and, for Q2, the products x_a x_b as well; the box description itself
+    is a box-tagged problem of the same degree"""
+    P = refined(dim, n, deg, lo, hi)
+    try:
+        d = P.desc
+        assert d.coarse.enabled and d.coarse.box_problem
+        box = C.cast(d.coarse.box_problem, C.POINTER(pk.Desc)).contents
+        assert box.box.enabled == 1 and list(box.box.n)[:dim] == list(n) and box.degree_u == deg and box.dim == dim and not box.coarse.enabled
+        nf = d.n_dofs_u // dim; nc = box.n_dofs_u // dim
+        ptr = np.ctypeslib.as_array(d.coarse.ptr, shape=(nf + 1,)); nnz = int(ptr[-1])
+        node = np.ctypeslib.as_array(d.coarse.node, shape=(nnz,)); w = np.ctypeslib.as_array(d.coarse.weight, shape=(nnz,))
+        assert ptr[0] == 0 and np.all(np.diff(ptr) >= 1) and node.min() >= 0 and node.max() < nc
+        Pm = sp.csr_matrix((w, node, ptr), shape=(nf, nc))
+        Xf = u_node_coords(P)
+        nn = [deg * n[a] + 1 for a in range(dim)]                      # lexicographic nodes of the box [-5, 5]^dim
+        grids = np.meshgrid(*[np.linspace(-5.0, 5.0, m) for m in nn], indexing="ij")
+        Xc = np.stack([g.transpose(*reversed(range(dim))).ravel() for g in grids], axis=1)     # x fastest
+        assert np.abs(Pm @ np.ones(nc) - 1.0).max() <= 1e-13
+        assert np.abs(Pm @ Xc - Xf).max() <= 1e-12
+        if deg == 2:
+            for a in range(dim):
+                for b in range(a, dim):
+                    assert np.abs(Pm @ (Xc[:, a] * Xc[:, b]) - Xf[:, a] * Xf[:, b]).max() <= 1e-11
+    finally:
+        P.close()

@@ -166,3 +166,24 @@ def test_slab_partition_tiles_the_global_box(dim, n, deg, ranks):
     assert (tot_cells, own_u, own_p) == (Pg.desc.n_cells, Pg.desc.n_dofs_u, Pg.desc.n_dofs_p)
     assert abs(z_hi - 5.0) < 1e-12
     Pg.close()
+
+
+def test_graded_box_carries_its_tensor_grid():
+    """poro_desc.tensor of the graded-box provider: no box tag, the 1D vertex grids of the tensor product are exactly the distinct vertex coordinates per direction
+    (the fast-diagonalisation preconditioners assemble their 1D matrices on them)"""
+    import numpy as np
+    from common import BC_3D, material
+    n, grading = (5, 4, 6), (1.5, 0.0, -0.8)
+    P = pk.Problem.graded_box(3, list(n), [10.0] * 3, 2, material(), BC_3D, list(grading))
+    try:
+        d = P.desc
+        assert d.box.enabled == 0 and d.tensor.enabled == 1 and list(d.tensor.n) == list(n)
+        X = np.ctypeslib.as_array(d.vertex_coords, shape=(d.n_vertices, 3))
+        for a in range(3):
+            g = np.ctypeslib.as_array(d.tensor.grid[a], shape=(n[a] + 1,))
+            assert np.all(np.diff(g) > 0) and abs(g[0] + 5.0) <= 1e-13 and abs(g[-1] - 5.0) <= 1e-13
+            assert np.abs(np.unique(np.round(X[:, a], 12)) - g).max() <= 1e-11
+            ratio = np.diff(g).max() / np.diff(g).min()
+            assert (ratio < 1 + 1e-9) == (grading[a] == 0.0)
+    finally:
+        P.close()
