@@ -142,6 +142,8 @@ typedef struct poro_partition {
 /* Closed affine constraints beyond the Dirichlet list: the hanging nodes of a locally refined mesh (DoFTools::make_hanging_node_constraints,
  * PoroElasticDisplacementSolver.h:112-113, PoroElasticPressureSolver.h:72-75; refine_mesh, PoroelasticityFSS.h:447-498).
  *   x[dof[i]] = sum_{k in ptr[i]..ptr[i+1]} weight[k] * x[master[k]] + inhomogeneity[i]
+ * (Partitioned runs, general form of poro_partition: every rank passes the entries whose constrained dof is local to it, and every master of such an entry must be
+ * local too - where none of the rank's cells touches a master it becomes a local dof of no local cell, listed in the interface lists of all ranks that hold it.)
  * exactly what ConstraintMatrix holds after close(): masters are unconstrained dofs, a constrained dof appears once and is not in the
  * Dirichlet list.  The library condenses at operator level (C^T A C on the free dofs, C^T b), which gives the same solution as
  * ConstraintMatrix::condense / distribute_local_to_global (:153, :168, PoroElasticDisplacementSolver.h:280-286), and distributes after each solve (:180, :306). */

@@ -267,9 +267,9 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
         la_rhs_u_finish(s, rhs, c->lift_u.p, c->neumann_u.p, c->dir_mask.p, c->n_u);
       }
     }
-    exchange_add(c, vec(c, PORO_VEC_RHS_U), c->n_u, c->comm.part.plane_u);
     if (c->cons_u.n) {
-      // condensed right-hand side C^T (b - A x_inh), x_inh = the constraints' inhomogeneities (distribute_local_to_global, :280-286)
+      // condensed right-hand side C^T (b - A x_inh), x_inh = the constraints' inhomogeneities (distribute_local_to_global, :280-286).  On a partition everything here is
+      // the rank's PARTIAL vector: rows are folded into their masters first, the interface sums come last (a rank may hold a master without holding the constrained dof)
       double *rhs = vec(c, PORO_VEC_RHS_U);
       if (c->cons_u.any_inhom) {
         la_fill(s, c->wd_u.p, 0.0, c->n_u); la_cons_expand(s, c->cons_u, c->wd_u.p, true);
@@ -280,6 +280,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
       }
       la_cons_reduce(s, c->cons_u, rhs);
     }
+    exchange_add(c, vec(c, PORO_VEC_RHS_U), c->n_u, c->comm.part.plane_u);
     // stream-ordered: the right-hand side is consumed by kernels of the same stream (a caller that wants the host to wait calls poro_ctx_synchronize)
     return 0;
   });
@@ -322,8 +323,9 @@ int poro_disp_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       if (!c->cons_u.n) return apply_A_u(c, x, y, mode, dp, false, dp ? c->scal.p : nullptr);
       // C^T A C: the search direction's hanging entries follow their masters, the product's hanging rows fold into the masters' rows
       la_cons_expand(c->stream, c->cons_u, const_cast<double *>(x), false);
-      apply_A_u(c, x, y, mode, nullptr, false, nullptr);
-      la_cons_reduce(c->stream, c->cons_u, y);
+      apply_A_u(c, x, y, mode, nullptr, false, nullptr, false);                 // the rank's partial product ...
+      la_cons_reduce(c->stream, c->cons_u, y);                                   // ... folded ...
+      exchange_add(c, y, c->n_u, c->comm.part.plane_u);                          // ... then summed over the interface
       return false;
     };
     if (opts->preconditioner == PORO_PREC_CHEBYSHEV) {
@@ -492,8 +494,8 @@ int poro_pres_assemble_residual(poro_ctx *c, double dt, double *l2) {
       if (c->operator_mode == PORO_OP_MATRIX_FREE && c->box.enabled) p_residual_stencil(s, c->dim, c->box, c->mat.k_over_mu, c->tmp_p.p, vec(c, PORO_VEC_P), c->src_local.p, R);
       else la_csr_residual(s, c->Ap, c->Mp.p, c->Kp.p, c->mat.k_over_mu, c->tmp_p.p, vec(c, PORO_VEC_P), c->src_local.p, R);
     }
+    la_cons_reduce(s, c->cons_p, R);                                              // constraints.condense(residual) (:153); partial rows first, interface sums after
     exchange_add(c, R, c->n_p, c->comm.part.plane_p);
-    la_cons_reduce(s, c->cons_p, R);                                              // constraints.condense(residual) (:153)
     if (c->n_pdir) la_mask_zero(s, R, c->pdir_mask.p, c->n_p);                    // prescribed-pressure rows are not part of the Newton system
     la_dot_partials(s, R, R, owned(c, c->n_p, c->comm.part.plane_p), c->partials.p);
     la_reduce_finish(s, c->partials.p, 1, c->red.p, 0);
@@ -545,8 +547,8 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       la_cons_expand(c->stream, c->cons_p, const_cast<double *>(x), false);      // condensed Jacobian C^T J C (:168)
       if (stencil) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(c->stream, c->dim, c->box, ja, jk, x, y); }
       else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Jp.p, x, y); }
-      exchange_add(c, y, c->n_p, c->comm.part.plane_p);
-      la_cons_reduce(c->stream, c->cons_p, y); return false;
+      la_cons_reduce(c->stream, c->cons_p, y);
+      exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
     };
     if (opts->preconditioner == PORO_PREC_FDM) {
       build_fdm_p(c);
@@ -619,7 +621,7 @@ int poro_proj_assemble_rhs(poro_ctx *c, const int32_t *tensor_components, int32_
           asm_proj_rhs(c->stream, a, c->color_cells.p + c->color_off[k], c->color_off[k + 1] - c->color_off[k], vec(c, PORO_VEC_U), n_comp, tensor_components, rhs);
       }
     }
-    for (int k = 0; k < n_comp; ++k) { exchange_add(c, rhs[k], c->n_p, c->comm.part.plane_p); la_cons_reduce(c->stream, c->cons_p, rhs[k]); }   // StrainProjector.h:191-194
+    for (int k = 0; k < n_comp; ++k) { la_cons_reduce(c->stream, c->cons_p, rhs[k]); exchange_add(c, rhs[k], c->n_p, c->comm.part.plane_p); }   // StrainProjector.h:191-194 (partial rows folded, then the interface sums)
     return 0;
   });
 }
@@ -639,8 +641,8 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
       la_cons_expand(c->stream, c->cons_p, const_cast<double *>(x), false);      // condensed projection matrix (StrainProjector.h:104-105)
       if (stencil) { Timed tm(c, "apply_p_stencil"); p_stencil_apply(c->stream, c->dim, c->box, 1.0, 0.0, x, y); }
       else { Timed tm(c, "apply_p_csr"); la_csr_spmv(c->stream, c->Ap, c->Mp.p, x, y); }
-      exchange_add(c, y, c->n_p, c->comm.part.plane_p);
-      la_cons_reduce(c->stream, c->cons_p, y); return false;
+      la_cons_reduce(c->stream, c->cons_p, y);
+      exchange_add(c, y, c->n_p, c->comm.part.plane_p); return false;
     };
     if (opts->preconditioner == PORO_PREC_FDM) {
       build_fdm_p(c);

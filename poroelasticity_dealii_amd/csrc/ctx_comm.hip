@@ -226,7 +226,7 @@ bool is_u_vec(int which) { return which == PORO_VEC_U || which == PORO_VEC_RHS_U
 
 // y = A_u x (+ interface exchange).  dot_partials != null asks for the block partials of x.y; returns true when they were produced
 // by the operator kernel itself (fused), false when the caller still has to launch the dot kernel.
-bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials, bool fix_rows, const PcgScalars *pcg_state) {
+bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials, bool fix_rows, const PcgScalars *pcg_state, bool exchange) {
   bool fused = false;
   if (mode == PORO_OP_MATRIX_FREE && c->box.enabled && c->mf_variant == 1 && kron_supported(c->dim, c->k_u)) {
     int slots;
@@ -248,7 +248,7 @@ bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_pa
     if (mode == PORO_OP_MATRIX_FREE) { mf_apply(c->stream, mf_args(c), x, y, true, dot_partials); fused = dot_partials != nullptr; }
     else la_csr_spmv(c->stream, c->Au, c->Au_val.p, x, y);
   }
-  exchange_add(c, y, c->n_u, c->comm.part.plane_u);
+  if (exchange) exchange_add(c, y, c->n_u, c->comm.part.plane_u);
   return fused;
 }
 

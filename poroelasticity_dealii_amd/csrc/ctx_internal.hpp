@@ -60,7 +60,8 @@ void mf_operator(poro_ctx *c, const double *x, double *y, bool constrained);
 double *vec(poro_ctx *c, int which);
 int64_t vec_len(poro_ctx *c, int which);
 bool is_u_vec(int which);
-bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr, bool fix_rows = true, const PcgScalars *pcg_state = nullptr);
+bool apply_A_u(poro_ctx *c, const double *x, double *y, int mode, double *dot_partials = nullptr, bool fix_rows = true, const PcgScalars *pcg_state = nullptr,
+               bool exchange = true /* false: leave the rank's partial product (the caller folds constrained rows first) */);
 
 // ---- Krylov drivers (ctx_pcg.hip) -----------------------------------------------------------------------------------------------------
 typedef std::function<bool(const double *, double *, double *)> ApplyFn;

@@ -201,7 +201,7 @@ void setup(poro_ctx *c, const poro_desc *d) {
     // hanging-node constraints (locally refined meshes): operator-level condensation, see include/poroel_hip.h poro_constraints
     if (d->cons_u.n || d->cons_p.n) {
       if (d->box.enabled) throw Error("constraint lists belong to general (non-box) meshes: assembled-CSR operator or the general matrix-free one");
-      if (c->comm.part.n_ranks > 1) throw Error("constraint lists are implemented for one rank");
+      if (c->comm.part.n_ranks > 1 && d->part.n_neighbours <= 0) throw Error("constraint lists on partitioned meshes need the general form of poro_partition (interface lists), with every master of a local constrained dof local as well");
     }
     upload_constraints(c->cons_u, d->cons_u, c->n_u, &m, "cons_u");
     { // extension: prescribed pressures (drained boundaries); the rows leave the pressure Newton system exactly like hanging rows do

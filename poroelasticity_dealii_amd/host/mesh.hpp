@@ -532,7 +532,6 @@ inline std::vector<int64_t> morton_cell_order(const Mesh &m) {
 inline void partition_problem(const ProblemData &G, int rank, int n_ranks, ProblemData &L) {
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::runtime_error("partition_problem: bad rank / n_ranks");
   if (G.part.n_ranks > 1) throw std::runtime_error("partition_problem: the problem is already a piece of a partition");
-  if (G.cons_u.n() || G.cons_p.n()) throw std::runtime_error("partition_problem: meshes with hanging-node constraints are not partitioned");
   if (!G.dirichlet_dof_p.empty()) throw std::runtime_error("partition_problem: prescribed pressures are implemented for one rank");
   const Mesh &gm = G.mesh; const int dim = gm.dim, nv = 1 << dim, k_u = G.dofs.k_u, dpc = ipow(k_u + 1, dim) * dim; const int64_t nc = gm.n_cells();
   if (nc < n_ranks) throw std::runtime_error("partition_problem: fewer cells than ranks");
@@ -546,7 +545,16 @@ inline void partition_problem(const ProblemData &G, int rank, int n_ranks, Probl
     for (auto &v : t) std::sort(v.begin(), v.end());
     return t;
   };
-  const auto tu = touching(G.dofs.cell_u, dpc, G.dofs.n_u), tp = touching(G.dofs.cell_p, nv, G.dofs.n_p);
+  auto tu = touching(G.dofs.cell_u, dpc, G.dofs.n_u), tp = touching(G.dofs.cell_p, nv, G.dofs.n_p);
+  // constraint lists (hanging nodes, ties; closed): a rank that holds a constrained dof must hold all of its masters, or it could neither expand x nor fold the row.  Masters that
+  // none of the rank's cells touch become GHOST dofs of the piece: local, shared with the ranks that do touch them (so the interface exchange keeps their values and row sums
+  // consistent), part of no local cell.  Each rank then condenses with its own complete slice of the list; partial rows are folded BEFORE the interface sums (the library's order)
+  auto add_ghost_masters = [&](std::vector<std::vector<int32_t>> &t, const ConstraintList &cl) {
+    for (int64_t i = 0; i < cl.n(); ++i) for (int32_t r : std::vector<int32_t>(t[cl.dof[i]])) for (int64_t k = cl.ptr[i]; k < cl.ptr[i + 1]; ++k) {
+      auto &v = t[cl.master[k]]; auto it = std::lower_bound(v.begin(), v.end(), r); if (it == v.end() || *it != r) v.insert(it, r);
+    }
+  };
+  add_ghost_masters(tu, G.cons_u); add_ghost_masters(tp, G.cons_p);
   auto has = [&](const std::vector<int32_t> &v) { return std::binary_search(v.begin(), v.end(), (int32_t)rank); };
   // local numbering: owned first, each group ascending in the global index
   auto number = [&](const std::vector<std::vector<int32_t>> &t, std::vector<int32_t> &l2g, std::vector<int32_t> &g2l, int64_t &n_owned) {
@@ -588,6 +596,20 @@ inline void partition_problem(const ProblemData &G, int rank, int n_ranks, Probl
     std::sort(dl.begin(), dl.end());
     for (auto &kv : dl) { L.dirichlet_dof.push_back(kv.first); L.dirichlet_value.push_back(kv.second); } }
   L.bc = G.bc; L.mat = G.mat;
+  // the rank's slice of the (closed) constraint lists in local numbering; ties were entered on the global problem already
+  auto localise = [&](const ConstraintList &cl, const std::vector<int32_t> &g2l, ConstraintList &out) {
+    out = ConstraintList{};
+    std::vector<std::pair<int32_t, int64_t>> mine;
+    for (int64_t i = 0; i < cl.n(); ++i) if (g2l[cl.dof[i]] >= 0) mine.emplace_back(g2l[cl.dof[i]], i);
+    std::sort(mine.begin(), mine.end());
+    for (auto &kv : mine) {
+      const int64_t i = kv.second; out.dof.push_back(kv.first); out.inhom.push_back(cl.inhom[i]);
+      for (int64_t k = cl.ptr[i]; k < cl.ptr[i + 1]; ++k) { if (g2l[cl.master[k]] < 0) throw std::runtime_error("partition_problem: a master is not local (internal error)"); out.master.push_back(g2l[cl.master[k]]); out.weight.push_back(cl.weight[k]); }
+      out.ptr.push_back((int64_t)out.master.size());
+    }
+  };
+  localise(G.cons_u, g2l_u, L.cons_u); localise(G.cons_p, g2l_p, L.cons_p);
+  L.ties_added = true;
   L.part = poro_partition{}; L.part.rank = rank; L.part.n_ranks = n_ranks; L.part.n_owned_u = own_u; L.part.n_owned_p = own_p;
   L.finalize(k_u, true);
 }

@@ -50,8 +50,11 @@ def csr_to_scipy(rp, col, val):
 
 
 def global_problem(mesh, deg):
-    """global (unpartitioned) problem of the general-partition tests: mesh = "gmsh" (the bundled domain.msh) | "box:nx,ny[,nz]" """
+    """global (unpartitioned) problem of the general-partition tests: mesh = "gmsh" (the bundled domain.msh) | "box:nx,ny[,nz]" | "refined:nx,ny[,nz]" (the box with its
+    middle block [n/4, 3n/4) refined once: hanging nodes)"""
     if mesh == "gmsh":
         return pk.Problem.gmsh(DOMAIN_MSH, deg, material(), BC_2D)
     n = [int(v) for v in mesh.split(":")[1].split(",")]
+    if mesh.startswith("refined:"):
+        return pk.Problem.refined_box(len(n), n, [10.0] * len(n), deg, material(), BC_2D if len(n) == 2 else BC_3D, [m // 4 for m in n], [max(3 * m // 4, m // 4 + 1) for m in n])
     return box_problem(len(n), n, deg)

@@ -94,12 +94,8 @@ def test_partition_bookkeeping():
 
 
 def test_partition_refusals():
-    """what the provider does not partition says so: hanging-node meshes, prescribed pressures, more ranks than cells, bad rank numbers"""
-    from common import BC_2D, box_problem, material
-    P = pk.Problem.refined_box(2, [4, 4], [10.0, 10.0], 2, material(), BC_2D, [1, 1], [3, 3])
-    with pytest.raises(RuntimeError, match="hanging-node"):
-        P.partition(0, 2)
-    P.close()
+    """what the provider does not partition says so: prescribed pressures, more ranks than cells, bad rank numbers"""
+    from common import box_problem
     P = box_problem(2, 3, 1); P.set_pressure_bc([(1, 0.0)])
     with pytest.raises(RuntimeError, match="prescribed pressures"):
         P.partition(0, 2)
@@ -112,6 +108,33 @@ def test_partition_refusals():
     one = P.partition(0, 1)                       # a single piece is the whole mesh, renumbered, without neighbours
     assert one.desc.part.n_neighbours == 0 and one.desc.n_dofs_u == P.desc.n_dofs_u and sorted(one.local_to_global_u) == list(range(P.desc.n_dofs_u))
     one.close(); P.close()
+
+
+def test_hanging_node_meshes_are_partitioned_with_ghost_masters():
+    """a refined box cut along the Morton curve: every piece gets its slice of the closed constraint lists in local numbering, and every master of a local constrained dof
+    is local too - as a GHOST dof (part of no local cell, shared with the ranks whose cells touch it) where the cut separates it from the hanging node"""
+    PG = global_problem("refined:4,4,4", 2)
+    world = 3
+    pieces = [PG.partition(r, world) for r in range(world)]
+    try:
+        dG = PG.desc
+        gdof = set(np.ctypeslib.as_array(dG.cons_u.dof, shape=(dG.cons_u.n,)).tolist())
+        seen, ghosts = set(), 0
+        for P in pieces:
+            d = P.desc; l2g = P.local_to_global_u
+            assert d.cons_u.n > 0 and d.part.n_neighbours > 0
+            dof = np.ctypeslib.as_array(d.cons_u.dof, shape=(d.cons_u.n,)); ptr = np.ctypeslib.as_array(d.cons_u.ptr, shape=(d.cons_u.n + 1,))
+            m = np.ctypeslib.as_array(d.cons_u.master, shape=(int(ptr[-1]),))
+            assert set(l2g[dof].tolist()) == gdof & set(l2g.tolist())             # exactly the constrained dofs this piece holds
+            assert m.min() >= 0 and m.max() < d.n_dofs_u and not set(m.tolist()) & set(dof.tolist())
+            seen |= set(l2g[dof].tolist())
+            in_cells = set(np.ctypeslib.as_array(d.cell_dofs_u, shape=(d.n_cells * 81,)).tolist())
+            ghosts += len(set(range(d.n_dofs_u)) - in_cells)
+        assert seen == gdof and ghosts > 0
+    finally:
+        for P in pieces:
+            P.close()
+        PG.close()
 
 
 def test_rigid_plate_ties_are_ordinary_constraint_entries():

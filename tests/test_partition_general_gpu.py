@@ -9,7 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world,mesh,deg,backend", [(2, "gmsh", 2, "hip_csr"), (3, "gmsh", 2, "hip_mf"), (3, "gmsh", 1, "hip_mf_cheb"), (4, "box:4,4,4", 2, "hip_mf"),
-                                                    (3, "box:4,5,3", 1, "hip_csr"), (2, "box:7,6", 2, "hip_mf_cheb")])
+                                                    (3, "box:4,5,3", 1, "hip_csr"), (2, "box:7,6", 2, "hip_mf_cheb"),
+                                                    # hanging-node meshes through the partition: ghost masters, rows folded before the interface sums
+                                                    (2, "refined:4,4", 2, "hip_csr"), (3, "refined:4,4,4", 2, "hip_mf"), (3, "refined:6,5", 1, "hip_mf_cheb"), (4, "refined:4,4,4", 1, "hip_csr")])
 def test_general_partition_on_one_gpu(tmp_path, world, mesh, deg, backend):
     R = run_ranks(tmp_path, world, mesh, deg, backend)
     check_against_single_rank(R, mesh, deg, tol_u=1e-8)
