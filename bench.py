@@ -307,7 +307,14 @@ def main():
         torch.cuda.set_device(local_rank)
         if world > 1:
             import torch.distributed as dist
-            dist.init_process_group(backend="gloo")   # control plane only (barrier, max, id broadcast); the data plane is RCCL inside the library
+            # control plane only (barrier, max, id broadcast); the data plane is RCCL inside the library.  gloo announces its connections on the C-level stdout, which must
+            # carry nothing but the one JSON line: file descriptor 1 points at stderr while the group is set up and its first collective runs
+            sys.stdout.flush(); saved_fd = os.dup(1); os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend="gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush(); os.dup2(saved_fd, 1); os.close(saved_fd)
     except ImportError:
         torch = None
 

@@ -87,6 +87,7 @@ def test_two_rank_rehearsal():
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cells", "8", "--share-gpu", "--config5-steps", "3"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:500]      # stdout carries the one JSON line and nothing else (gloo's connection messages go to stderr)
     d = _line(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "8x8x8" in d["config"]["workload"]                      # strong scaling: the BASELINE mesh itself is cut into slabs
