@@ -192,7 +192,12 @@ def run_case(args, scaling, steps, warmup, rank, world, local_rank, torch, dist,
             recv[:] = tr.numpy()
         G.comm_callbacks(_allreduce, _sendrecv)
     elif world > 1:
-        G.comm_rccl(rccl_ids[label + scaling])
+        # (RCCL prints a version banner on the C-level stdout when a communicator is created: keep stdout for the JSON line)
+        sys.stdout.flush(); saved_fd = os.dup(1); os.dup2(2, 1)
+        try:
+            G.comm_rccl(rccl_ids[label + scaling])
+        finally:
+            os.dup2(saved_fd, 1); os.close(saved_fd)
 
     part = P.desc.part                        # shared interface planes are counted once, by their upper owner
     own_u = P.desc.n_dofs_u - (part.plane_u if part.has_upper else 0)
