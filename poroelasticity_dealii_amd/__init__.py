@@ -176,6 +176,8 @@ def load_host():
         L.poro_host_build_refined_box.argtypes = [C.c_int, _ip, _dp, C.c_int, _ip, _ip] + bc
         L.poro_host_build_gmsh.restype = C.c_void_p
         L.poro_host_build_gmsh.argtypes = [C.c_char_p, C.c_int] + bc
+        L.poro_host_build_gmsh_refined.restype = C.c_void_p
+        L.poro_host_build_gmsh_refined.argtypes = [C.c_char_p, C.c_int, C.c_int] + bc
         L.poro_host_set_pressure_bc.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
         L.poro_host_tie_boundary.argtypes = [C.c_void_p, C.c_int, _ip, _ip]
         L.poro_host_partition.restype = C.c_void_p
@@ -271,8 +273,12 @@ class Problem:
         return cls(load_host().poro_host_build_refined_box(dim, pn, ps, degree_u, plo, phi, *args, C.byref(material)))
 
     @classmethod
-    def gmsh(cls, path, degree_u, material, dirichlet, neumann=()):
+    def gmsh(cls, path, degree_u, material, dirichlet, neumann=(), refine=0):
+        """Gmsh 2.2 quadrilateral mesh (read_mesh, PoroelasticityFSS.h:438-445), optionally after `refine` uniform refinements.  Where the mesh fills a rectangle whose sides
+        carry the colorized boundary ids the descriptor also gets an auxiliary uniform box as coarse space (poro_desc.coarse -> PREC_TWO_LEVEL)"""
         keep, args = cls._bc(dirichlet, neumann)
+        if refine:
+            return cls(load_host().poro_host_build_gmsh_refined(path.encode(), degree_u, int(refine), *args, C.byref(material)))
         return cls(load_host().poro_host_build_gmsh(path.encode(), degree_u, *args, C.byref(material)))
 
     def partition(self, rank, n_ranks):

@@ -278,7 +278,9 @@ k_fdmu_reg(FdmuPass P, const double *__restrict__ in, double *__restrict__ out) 
     double b2[Gm::KKP];
     const double *lam_lane = P.lam_d[c]; const double kdc = P.kd[c];
 #pragma unroll
-    for (int mt = 0; mt < Gm::MT; ++mt) {     // D register (mt, q) of this lane = B operand of k-step 4 mt + q
+    for (int mt = 0; mt < NCH; ++mt) {        // D register (mt, q) of this lane = B operand of k-step 4 mt + q.  (Tiles come in pairs: with an odd number of chunks the last tile, mt = NCH, holds rows
+                                              //  behind the line's end only - exact zeros - and b2 has no k-steps for it: looping to MT wrote past b2, which broke lines of 33-48, 65-80, ... points in this
+                                              //  non-symmetric form until round 3)
       double den[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) den[q] = fma(kdc, lam_lane[min(16 * mt + kq + 4 * q, k_last)], base);   // removed modes carry lam = inf -> factor 0

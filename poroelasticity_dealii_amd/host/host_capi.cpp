@@ -74,6 +74,22 @@ void *poro_host_build_gmsh(const char *path, int k_u,
     P->mat = *mat;
     P->mesh = read_gmsh22(path);
     P->finalize(k_u);
+    attach_auxiliary_box(*P, k_u);     // (where the mesh fills a rectangle with colorized side ids: coarse space of the two-level preconditioner)
+    return P;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+// the same mesh after `refine` uniform refinements (refine_global of read_mesh()'s grid)
+void *poro_host_build_gmsh_refined(const char *path, int k_u, int refine,
+                                   int n_dir, const int32_t *dl, const int32_t *dc, const double *dv,
+                                   int n_neu, const int32_t *nl, const int32_t *nc, const double *nv, const poro_material *mat) {
+  try {
+    auto *P = new ProblemData();
+    fill_bc(P->bc, n_dir, dl, dc, dv, n_neu, nl, nc, nv);
+    P->mat = *mat;
+    P->mesh = read_gmsh22(path);
+    for (int r = 0; r < refine; ++r) P->mesh = refine_quads(P->mesh);
+    P->finalize(k_u);
+    attach_auxiliary_box(*P, k_u);
     return P;
   } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }

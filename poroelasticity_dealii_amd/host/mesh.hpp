@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdint>
 #include <fstream>
+#include <limits>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -122,6 +123,35 @@ inline Mesh read_gmsh22(const std::string &path) {
     }
   }
   return m;
+}
+
+// One uniform refinement of a 2D quadrilateral mesh (Triangulation::refine_global(1) for read_mesh()'s grid): every cell becomes its four children around the cell
+// centre, edge midpoints are shared, boundary edges pass their id to both halves
+inline Mesh refine_quads(const Mesh &m) {
+  if (m.dim != 2) throw std::runtime_error("refine_quads: 2D meshes only");
+  Mesh r; r.dim = 2; r.vertices = m.vertices;
+  std::map<std::pair<int32_t, int32_t>, int32_t> mid;
+  auto midpoint = [&](int32_t a, int32_t b) {
+    auto key = std::make_pair(std::min(a, b), std::max(a, b));
+    auto it = mid.find(key); if (it != mid.end()) return it->second;
+    const int32_t id = (int32_t)(r.vertices.size() / 2);
+    for (int d = 0; d < 2; ++d) r.vertices.push_back(0.5 * (m.vertices[2 * a + d] + m.vertices[2 * b + d]));
+    mid[key] = id; return id;
+  };
+  const int64_t nc = m.n_cells();
+  for (int64_t c = 0; c < nc; ++c) {
+    const int32_t *v = &m.cells[4 * c];
+    const int32_t e02 = midpoint(v[0], v[2]), e13 = midpoint(v[1], v[3]), e01 = midpoint(v[0], v[1]), e23 = midpoint(v[2], v[3]);
+    const int32_t cc = (int32_t)(r.vertices.size() / 2);
+    for (int d = 0; d < 2; ++d) r.vertices.push_back(0.25 * (m.vertices[2 * v[0] + d] + m.vertices[2 * v[1] + d] + m.vertices[2 * v[2] + d] + m.vertices[2 * v[3] + d]));
+    const int32_t ch[4][4] = {{v[0], e01, e02, cc}, {e01, v[1], cc, e13}, {e02, cc, v[2], e23}, {cc, e13, e23, v[3]}};
+    for (auto &q : ch) r.cells.insert(r.cells.end(), q, q + 4);
+  }
+  static const int kids[4][2] = {{0, 2}, {1, 3}, {0, 1}, {2, 3}};     // children of a parent along its local face 0..3
+  for (size_t f = 0; f < m.bface_cell.size(); ++f) for (int h = 0; h < 2; ++h) {
+    r.bface_cell.push_back(4 * m.bface_cell[f] + kids[m.bface_local[f]][h]); r.bface_local.push_back(m.bface_local[f]); r.bface_id.push_back(m.bface_id[f]);
+  }
+  return r;
 }
 
 // DoFHandler::distribute_dofs + cell->get_dof_indices for FESystem(FE_Q(k_u),dim) and FE_Q(1).
@@ -461,6 +491,68 @@ inline void build_box_problem(ProblemData &P, int dim, const int n[3], const dou
   for (int d = 0; d < sd; ++d) { pu *= (k_u * n[d] + 1); pp *= (n[d] + 1); }
   P.part.plane_u = pu; P.part.plane_p = pp;
   P.finalize(k_u);
+}
+
+// Auxiliary coarse space for a general 2D mesh that fills a rectangle whose sides carry one boundary id each, in the colorized order (x low, x high, y low, y high = 0..3):
+// a uniform box of about as many cells with the same boundary conditions, and the box's FE functions evaluated at every displacement node of the mesh (poro_coarse_space).
+// The spaces are not nested; that is what the two-level preconditioner's smoother is for (auxiliary-space preconditioning).  Returns false (and attaches nothing) when
+// the geometry or the labels do not fit.
+inline bool attach_auxiliary_box(ProblemData &P, int k_u) {
+  const Mesh &m = P.mesh; const int dim = m.dim;
+  if (dim != 2 || m.box.enabled || P.cons_u.n() || P.part.n_ranks > 1) return false;
+  double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+  for (int64_t v = 0; v < m.n_vertices(); ++v) for (int d = 0; d < 2; ++d) { lo[d] = std::min(lo[d], m.vertices[2 * v + d]); hi[d] = std::max(hi[d], m.vertices[2 * v + d]); }
+  const double size[2] = {hi[0] - lo[0], hi[1] - lo[1]};
+  if (!(size[0] > 0 && size[1] > 0)) return false;
+  static const int fv[4][2] = {{0, 2}, {1, 3}, {0, 1}, {2, 3}};
+  // every boundary edge lies on one side of the rectangle, and a boundary id names ONE side (Gmsh numbers the sides of domain.msh counter-clockwise from the bottom,
+  // hyper_rectangle(colorize) by direction): the box gets the mesh's conditions with the ids translated to its own
+  std::map<int, int> side_of_id;
+  for (size_t f = 0; f < m.bface_cell.size(); ++f) {
+    const int32_t va = m.cells[4 * m.bface_cell[f] + fv[m.bface_local[f]][0]], vb = m.cells[4 * m.bface_cell[f] + fv[m.bface_local[f]][1]];
+    int side = -1;
+    for (int d = 0; d < 2 && side < 0; ++d) for (int hs = 0; hs < 2; ++hs) {
+      const double want = hs ? hi[d] : lo[d];
+      if (std::fabs(m.vertices[2 * va + d] - want) <= 1e-9 * size[d] && std::fabs(m.vertices[2 * vb + d] - want) <= 1e-9 * size[d]) { side = 2 * d + hs; break; }
+    }
+    if (side < 0) return false;                                 // (a hole, a curved or slanted boundary: not a rectangle)
+    auto it = side_of_id.find(m.bface_id[f]);
+    if (it == side_of_id.end()) side_of_id[m.bface_id[f]] = side; else if (it->second != side) return false;
+  }
+  auto translate = [&](std::vector<int32_t> &labels) { for (auto &l : labels) { auto it = side_of_id.find(l); l = it == side_of_id.end() ? -1 - l : it->second; } };   // (ids no edge carries: to ids the box does not have)
+  const int nside = std::max(2, (int)std::lround(std::sqrt((double)m.n_cells() * size[0] / size[1])));
+  int n[3] = {nside, std::max(2, (int)std::lround((double)m.n_cells() / nside)), 1};
+  double origin[3] = {lo[0], lo[1], 0}, h[3] = {size[0] / n[0], size[1] / n[1], 1};
+  P.coarse.reset(new ProblemData()); ProblemData &C = *P.coarse;
+  C.bc = P.bc; C.mat = P.mat;
+  translate(C.bc.dirichlet_labels); translate(C.bc.neumann_labels); translate(C.bc.pressure_labels); translate(C.bc.tie_labels);
+  C.mesh = make_box(dim, n, origin, h, true, true);
+  C.part = poro_partition{}; C.part.n_ranks = 1;
+  C.finalize(k_u);
+  // displacement nodes of the mesh: positions by the cells' Q1 maps of the reference nodes
+  const int n1 = k_u + 1, ns = ipow(n1, dim); const int64_t nn = P.dofs.n_u / dim;
+  std::vector<double> X((size_t)nn * 2, std::numeric_limits<double>::quiet_NaN());
+  for (int64_t c = 0; c < m.n_cells(); ++c) for (int s = 0; s < ns; ++s) {
+    const int64_t node = P.dofs.cell_u[(c * ns + s) * dim] / dim;
+    if (X[2 * node] == X[2 * node]) continue;
+    const double a = (double)(s % n1) / k_u, b = (double)(s / n1) / k_u, w[4] = {(1 - a) * (1 - b), a * (1 - b), (1 - a) * b, a * b};
+    for (int d = 0; d < 2; ++d) { double x = 0; for (int v = 0; v < 4; ++v) x += w[v] * m.vertices[2 * m.cells[4 * c + v] + d]; X[2 * node + d] = x; }
+  }
+  const int64_t nn0 = (int64_t)k_u * n[0] + 1;
+  std::vector<double> val(ns), grad((size_t)ns * dim);
+  P.prol_ptr.assign(1, 0); P.prol_node.clear(); P.prol_w.clear();
+  for (int64_t i = 0; i < nn; ++i) {
+    int c[2]; double xi[2];
+    for (int d = 0; d < 2; ++d) { const double t = (X[2 * i + d] - origin[d]) / h[d]; c[d] = std::min(std::max((int)std::floor(t), 0), n[d] - 1); xi[d] = std::min(std::max(t - c[d], 0.0), 1.0); }
+    shape_at(dim, k_u, xi, val.data(), grad.data());
+    for (int s = 0; s < ns; ++s) if (std::fabs(val[s]) > 1e-13) {
+      P.prol_node.push_back((int32_t)((int64_t)(k_u * c[1] + s / n1) * nn0 + (k_u * c[0] + s % n1))); P.prol_w.push_back(val[s]);
+    }
+    P.prol_ptr.push_back((int64_t)P.prol_node.size());
+  }
+  P.d.coarse = poro_coarse_space{}; P.d.coarse.enabled = 1; P.d.coarse.box_problem = &C.d;
+  P.d.coarse.ptr = P.prol_ptr.data(); P.d.coarse.node = P.prol_node.data(); P.d.coarse.weight = P.prol_w.data();
+  return true;
 }
 
 // Graded box: the colorized box with its vertices moved by x -> origin + size * (exp(g t) - 1) / (exp(g) - 1), t in [0, 1], per direction (g = 0: unchanged).

@@ -134,3 +134,38 @@ def test_graded_box_keeps_the_fast_diagonalisation(deg, n, grading):
             assert np.linalg.norm(F.get(pk.VEC_STRAIN0 + e) - O.get(pk.VEC_STRAIN0 + e)) <= 1e-9 * np.linalg.norm(O.get(pk.VEC_STRAIN0 + e))
     finally:
         F.close(); G.close(); O.close(); P.close(); U.close()
+
+
+def test_gmsh_mesh_two_level_preconditioner_is_mesh_independent():
+    """read_mesh()'s grid (domain.msh: unstructured numbering, Gmsh's boundary ids) and its uniform refinements: the descriptor carries an auxiliary uniform box with the
+    same boundary conditions (ids translated side by side) as coarse space; PREC_TWO_LEVEL = Jacobi + block fast diagonalisation of that box through the FE interpolation.
+    The CG iteration count stays flat under refinement (Jacobi's doubles), the solution is the oracle's"""
+    from common import BC_2D, DOMAIN_MSH, material
+    counts, jacobi = [], []
+    for r in (0, 1, 2, 3):
+        P = pk.Problem.gmsh(DOMAIN_MSH, 2, material(), BC_2D, refine=r)
+        assert P.desc.coarse.enabled and not P.desc.box.enabled
+        F = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+        O = oracle_py.Oracle(P, hoisted=True) if r <= 1 else None
+        try:
+            assert F.supports_preconditioner(0, pk.PREC_TWO_LEVEL) and not F.supports_preconditioner(0, pk.PREC_FDM)
+            p = REF["p_init"] * (1 + 0.2 * np.sin(0.37 * np.arange(F.n_p)))
+            F.set(pk.VEC_P, p); F.disp_assemble_system(True)
+            rc, info = F.disp_solve(abs_tol=1e-14, rel_tol=1e-10, max_iter=500, prec=pk.PREC_TWO_LEVEL)
+            assert rc == 0
+            counts.append(info.iterations); u = F.get(pk.VEC_U)
+            F.fill(pk.VEC_U, 0.0)
+            rc, info = F.disp_solve(abs_tol=1e-14, rel_tol=1e-10, max_iter=50000)
+            assert rc == 0 and np.linalg.norm(F.get(pk.VEC_U) - u) <= 1e-7 * np.linalg.norm(u)
+            jacobi.append(info.iterations)
+            if O is not None:
+                O.set(pk.VEC_P, p); O.disp_assemble_system(True)
+                assert O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=50000)[0] == 0
+                assert np.linalg.norm(u - O.get(pk.VEC_U)) <= 1e-8 * np.linalg.norm(u)
+        finally:
+            F.close(); P.close()
+            if O is not None:
+                O.close()
+    print("Gmsh mesh, two-level CG iterations per refinement:", counts, "Jacobi:", jacobi)
+    assert all(b <= 1.3 * a for a, b in zip(counts, counts[1:])), counts
+    assert counts[-1] < jacobi[-1] / 5, (counts, jacobi)
