@@ -15,8 +15,8 @@ for r in range(int(sys.argv[1]) + 1 if len(sys.argv) > 1 else 6):
     rec = {"refinements": r, "n_cells": int(P.desc.n_cells), "n_dofs_u": int(P.desc.n_dofs_u)}
     G.set(pk.VEC_P, bench.INPUT["p_init"] * (1 + 0.2 * np.sin(0.37 * np.arange(G.n_p)))); G.disp_assemble_system(True)
     for name, prec, cap in (("two_level", pk.PREC_TWO_LEVEL, 1000), ("chebyshev", pk.PREC_CHEBYSHEV, 20000), ("jacobi", pk.PREC_JACOBI, 200000)):
-        if name == "jacobi" and r > 4:
-            continue
+        if not G.supports_preconditioner(0, prec):       # (the box's lines pass 320 points at r = 4: with different conditions at their two ends only the nodal kernels of up to 320 points apply)
+            rec[name] = "not supported at this size"; continue
         best = None
         for rep in range(2):
             G.fill(pk.VEC_U, 0.0); G.synchronize(); t0 = time.perf_counter()
