@@ -381,7 +381,7 @@ void fdmo_scalar_init_slab(FdmOct &O, const int nn[3], int rank, const std::vect
 void fdmo_scalar_slab_pass(hipStream_t s, FdmOct &O, int pass, double a, double kappa, const double *in, double *out);
 // planar (2D) form: quadrant layout with one plane and 2 components; four batched GEMM launches per application
 bool fdmo_planar_usable(int dim, const int nn[3]);
-void fdmo_init_planar(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s);
+void fdmo_init_planar(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s, bool split = true /* false: different conditions at the two ends of some line - no parity split, full-length transforms */);
 bool fdmo_upload_dir_planar(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn);
 void fdmo_apply_planar(hipStream_t s, const FdmOct &O, const double *g_q, double *z_q, const PcgScalars *gate = nullptr);
 void fdmo_from_nodal(hipStream_t s, const FdmOct &O, const double *v_nodal, double *q_oct);   // q = H v (node-interleaved vector -> octant form)

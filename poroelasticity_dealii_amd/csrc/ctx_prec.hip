@@ -222,7 +222,7 @@ void analyse_fdm_u(poro_ctx *c) {
   // Checked here, after the ranks have agreed on the face flags, so that poro_supports_preconditioner() is authoritative and no rank throws alone at solve time
   if (why.empty()) for (int d = 0; d < dim; ++d) {
     const int64_t line = (multi && d == last) ? 0 : nn[d];        // (the partitioned direction's GLOBAL line length is only known in build_fdm_u; its limit of 4096 is checked there on every rank alike)
-    if (line > 320) for (int comp = 0; comp < dim; ++comp) if (F.fix[comp][d][0] != F.fix[comp][d][1]) why = "a grid line of more than 320 points needs the same Dirichlet condition at both of its ends (even / odd transforms)";
+    if (line > 320 && !(dim == 2 && !multi)) for (int comp = 0; comp < dim; ++comp) if (F.fix[comp][d][0] != F.fix[comp][d][1]) why = "a grid line of more than 320 points needs the same Dirichlet condition at both of its ends (even / odd transforms)";   // (2D on one rank: the planar form takes lines of any length with any end conditions)
   }
   if (why.empty()) for (int comp = 0; comp < dim; ++comp) {
     bool any = false;
@@ -271,12 +271,15 @@ void build_fdm_u(poro_ctx *c) {
   // octant form (kernels_fdmo.hip): one rank, 3D, every direction mirror-symmetric for every component, half lines of at most 128 entries
   // slab partitions: the quadrant form (x, y split locally; the z butterfly next to the all-to-all) under the same conditions on the GLOBAL line
   bool oct_ok = !F.single && !std::getenv("PORO_FDMU_NO_OCT");
-  bool planar = false;     // 2D, one rank: the quadrant form with a single plane, transforms as batched GEMMs (lines of any length)
+  bool planar = false, planar_split = true;     // 2D, one rank: the quadrant form with a single plane, transforms as batched GEMMs (lines of any length; without the parity split where the end conditions differ)
   { int nn3[3] = {F.nn[0], F.nn[1], F.nn[2]}, sym3[3] = {F.nn[0], F.nn[1], multi ? F.ng : F.nn[2]};
     planar = dim == 2 && !multi && fdmo_planar_usable(dim, nn3);
     oct_ok = oct_ok && (planar || fdmo_usable(dim, sym3));
-    for (int d = 0; d < dim && oct_ok; ++d) for (int comp = 0; comp < dim; ++comp) oct_ok = oct_ok && F.fix[comp][d][0] == F.fix[comp][d][1];
-    if (oct_ok && planar) fdmo_init_planar(c->fdm_oct, nn3, F.coef, c->stream);
+    bool symmetric = true;
+    for (int d = 0; d < dim; ++d) for (int comp = 0; comp < dim; ++comp) symmetric = symmetric && F.fix[comp][d][0] == F.fix[comp][d][1];
+    planar_split = symmetric;
+    if (!planar) oct_ok = oct_ok && symmetric;      // (the planar form also runs without the parity split; the 3D forms need it)
+    if (oct_ok && planar) fdmo_init_planar(c->fdm_oct, nn3, F.coef, c->stream, planar_split);
     else if (oct_ok && !multi) fdmo_init(c->fdm_oct, nn3, F.coef, c->stream);
     if (oct_ok && multi) { std::vector<int> node_layers(F.n_ranks); for (int q = 0; q < F.n_ranks; ++q) node_layers[q] = ku * F.layers[q];
                            fdmo_init_slab(c->fdm_oct, nn3, F.coef, F.rank, node_layers, c->comm.part.has_upper != 0, c->stream); } }
@@ -295,7 +298,7 @@ void build_fdm_u(poro_ctx *c) {
         const int key = F.fix[comp][d][0] * 2 + F.fix[comp][d][1];
         if (!have[key]) { fdmu_eig_1d(ku, hcell, F.fix[comp][d][0], F.fix[comp][d][1], S[key], lam[key]); have[key] = true; }
         FdmuDir &D = global_dir ? F.last_global[comp] : F.dir[comp][d];
-        fdmu_upload_dir(D, S[key], lam[key], nnode, global_dir ? false : F.single, allow_split);
+        if (!(planar && oct_ok && nnode > 320 && !allow_split)) fdmu_upload_dir(D, S[key], lam[key], nnode, global_dir ? false : F.single, allow_split);   // (the nodal kernels have no full-length form beyond 320 points; the planar form does not need them)
         all_split = all_split && D.split;
         if (oct_ok && attempt == 0) oct_ok = planar ? fdmo_upload_dir_planar(c->fdm_oct, comp, d, S[key], lam[key], nnode) : fdmo_upload_dir(c->fdm_oct, comp, d, S[key], lam[key], nnode);
       }

@@ -70,7 +70,7 @@ struct OctPos {
   __device__ __forceinline__ OctPos(const OctDims &D, int64_t idx) {
     const int kx = (int)(idx % D.hxp), ky = (int)((idx / D.hxp) % D.hy), kz = (int)(idx / ((int64_t)D.hxp * D.hy));
     valid = kx < D.hx;
-    const int mx = D.nx - 1 - kx, my = D.ny - 1 - ky, mz = D.no == 8 ? D.nz - 1 - kz : kz;
+    const int mx = D.no == 1 ? kx : D.nx - 1 - kx, my = D.no == 1 ? ky : D.ny - 1 - ky, mz = D.no == 8 ? D.nz - 1 - kz : kz;   // (no = 1: no direction is split - the plain nodal values in planar storage)
     centre[0] = mx == kx; centre[1] = my == ky; centre[2] = mz == kz; own = kz < D.own_z;
     weight = (centre[0] ? 1.0 : 0.5) * (centre[1] ? 1.0 : 0.5) * (centre[2] ? 1.0 : 0.5);   // |v|^2 over a mirror orbit = weight * sum of the squared parity parts
 #pragma unroll
@@ -1051,17 +1051,23 @@ void fdmo_scalar_slab_pass(hipStream_t s, FdmOct &O, int pass, double a, double 
                                               else hipLaunchKernelGGL(kernel<3>, oct_grid((O).co_stride, 3), kBlock, 0, s, dims_of(O), __VA_ARGS__); } while (0)
 // ---- planar form, host side: quadrant layout Q[c][2 py + px][ky][kx] (one plane), transforms as row-major h x h matrices F[mode][node] per (component, direction, parity) ----
 bool fdmo_planar_usable(int dim, const int nn[3]) { return dim == 2 && nn[0] >= 2 && nn[1] >= 2 && nn[0] <= 4096 && nn[1] <= 4096; }
-void fdmo_init_planar(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s) {
-  O.nc = 2; O.no = 4; O.planar = true;
-  for (int d = 0; d < 3; ++d) { O.n[d] = d < 2 ? nn[d] : 1; O.h[d] = d < 2 ? (nn[d] + 1) / 2 : 1; for (int c = 0; c < 3; ++c) O.coef[c][d] = coef[c][d]; }
+void fdmo_init_planar(FdmOct &O, const int nn[3], const double coef[3][3], hipStream_t s, bool split) {
+  O.nc = 2; O.no = split ? 4 : 1; O.planar = true;
+  for (int d = 0; d < 3; ++d) { O.n[d] = d < 2 ? nn[d] : 1; O.h[d] = d < 2 ? (split ? (nn[d] + 1) / 2 : nn[d]) : 1; for (int c = 0; c < 3; ++c) O.coef[c][d] = coef[c][d]; }
   O.nt = 0; O.hxp = (O.h[0] + 1) & ~1; O.own_z = 1;
-  O.co_stride = (int64_t)O.hxp * O.h[1]; O.n_oct = 8 * O.co_stride;
+  O.co_stride = (int64_t)O.hxp * O.h[1]; O.n_oct = 2 * O.no * O.co_stride;
   O.g.alloc(O.n_oct); O.z.alloc(O.n_oct); O.t.alloc(2 * O.n_oct);
   O.g.zero(s); O.z.zero(s); O.t.zero(s);
 }
 bool fdmo_upload_dir_planar(FdmOct &O, int comp, int dir, const std::vector<double> &S, const std::vector<double> &lam, int nn) {
-  const int h = (nn + 1) / 2;
   if (nn != O.n[dir]) throw Error("fdmo_upload_dir_planar: line length mismatch");
+  if (O.no == 1) {          // no parity split (different conditions at the two ends of a line): the full transform F[mode][node], modes that do not exist carry lam = inf
+    std::vector<double> F((size_t)nn * nn, 0.0), lp((size_t)nn + 16, std::numeric_limits<double>::infinity());
+    for (int m = 0; m < nn; ++m) { if (!(lam[m] < 1e300)) continue; for (int k = 0; k < nn; ++k) F[(size_t)m * nn + k] = S[(size_t)k * nn + m]; lp[m] = lam[m]; }
+    O.h_lam[comp][dir][0] = lp; O.fwd[comp][dir][0].upload(F); O.lam[comp][dir][0].upload(lp);
+    return true;
+  }
+  const int h = (nn + 1) / 2;
   std::vector<int> grp[2];
   for (int m = 0; m < nn; ++m) {
     if (!(lam[m] < 1e300)) continue;
@@ -1082,29 +1088,30 @@ bool fdmo_upload_dir_planar(FdmOct &O, int comp, int dir, const std::vector<doub
 void fdmo_apply_planar(hipStream_t s, const FdmOct &O, const double *g, double *z, const PcgScalars *gate) {
   const int hx = O.h[0], hy = O.h[1], hxp = O.hxp; const int64_t co = O.co_stride;
   double *t1 = O.t.p, *t2 = O.t.p + O.n_oct;
-  Gemm2D G{}; G.nb = 8; G.gate = gate; G.rsC = hxp;
+  const int no = O.no, nb = 2 * no;                 // blocks: (component, quadrant) - or the two components alone without the parity split
+  Gemm2D G{}; G.nb = nb; G.gate = gate; G.rsC = hxp;
   auto launch = [&](bool ak, bool bk) {
-    const dim3 grid((unsigned)(((G.M + 63) / 64) * ((G.N + 63) / 64)), 8);
+    const dim3 grid((unsigned)(((G.M + 63) / 64) * ((G.N + 63) / 64)), (unsigned)nb);
     if (ak && bk) hipLaunchKernelGGL((k_fdmo_gemm2d<true, true>), grid, 256, 0, s, G);
     else if (ak) hipLaunchKernelGGL((k_fdmo_gemm2d<true, false>), grid, 256, 0, s, G);
     else hipLaunchKernelGGL((k_fdmo_gemm2d<false, false>), grid, 256, 0, s, G);
   };
   // 1: T[ky][mx] = sum_kx X[ky][kx] Fx[mx][kx]
   G.M = hy; G.N = hx; G.K = hx; G.rsA = hxp; G.csA = 1; G.rsB = 1; G.csB = hx; G.scale = 0;
-  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.A[b] = g + (int64_t)b * co; G.B[b] = O.fwd[c][0][q & 1].p; G.C[b] = t1 + (int64_t)b * co; }
+  for (int b = 0; b < nb; ++b) { const int c = b / no, q = b % no; G.A[b] = g + (int64_t)b * co; G.B[b] = O.fwd[c][0][q & 1].p; G.C[b] = t1 + (int64_t)b * co; }
   launch(true, true);
   // 2: U[my][mx] = sum_ky Fy[my][ky] T[ky][mx], divided by the eigenvalue sums
   G.M = hy; G.N = hx; G.K = hy; G.rsA = hy; G.csA = 1; G.rsB = hxp; G.csB = 1; G.scale = 1;
-  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.A[b] = O.fwd[c][1][q >> 1].p; G.B[b] = t1 + (int64_t)b * co; G.C[b] = t2 + (int64_t)b * co;
+  for (int b = 0; b < nb; ++b) { const int c = b / no, q = b % no; G.A[b] = O.fwd[c][1][q >> 1].p; G.B[b] = t1 + (int64_t)b * co; G.C[b] = t2 + (int64_t)b * co;
                                 G.lamM[b] = O.lam[c][1][q >> 1].p; G.lamN[b] = O.lam[c][0][q & 1].p; G.cM[b] = O.coef[c][1]; G.cN[b] = O.coef[c][0]; }
   launch(true, false);
   // 3: V[ky][mx] = sum_my Fy[my][ky] U[my][mx]
   G.rsA = 1; G.csA = hy; G.scale = 0;
-  for (int b = 0; b < 8; ++b) { G.B[b] = t2 + (int64_t)b * co; G.C[b] = t1 + (int64_t)b * co; }
+  for (int b = 0; b < nb; ++b) { G.B[b] = t2 + (int64_t)b * co; G.C[b] = t1 + (int64_t)b * co; }
   launch(false, false);
   // 4: Z[ky][kx] = sum_mx V[ky][mx] Fx[mx][kx]
   G.M = hy; G.N = hx; G.K = hx; G.rsA = hxp; G.csA = 1; G.rsB = hx; G.csB = 1;
-  for (int b = 0; b < 8; ++b) { const int c = b >> 2, q = b & 3; G.A[b] = t1 + (int64_t)b * co; G.B[b] = O.fwd[c][0][q & 1].p; G.C[b] = z + (int64_t)b * co; }
+  for (int b = 0; b < nb; ++b) { const int c = b / no, q = b % no; G.A[b] = t1 + (int64_t)b * co; G.B[b] = O.fwd[c][0][q & 1].p; G.C[b] = z + (int64_t)b * co; }
   launch(true, false);
 }
 

@@ -19,7 +19,7 @@ MIXED_2D = [(0, 0, 0.0), (2, 1, 0.0), (3, 0, 1e-6)]
 CASES = [(3, (4, 3, 5), 2, BC_3D), (3, (5, 4, 3), 1, BC_3D), (3, (3, 4, 2), 2, MIXED_3D), (2, (6, 5), 2, BC_2D), (2, (7, 4), 1, MIXED_2D), (3, (9, 2, 3), 2, BC_3D),
          (2, (100, 90), 2, BC_2D), (3, (170, 3, 2), 1, BC_3D), (2, (5, 230), 1, BC_2D), (2, (168, 3), 2, BC_2D),
          (3, (100, 3, 2), 2, BC_3D), (3, (2, 120, 3), 2, BC_3D), (3, (3, 2, 110), 2, BC_3D), (3, (84, 3, 50), 2, BC_3D),
-         (2, (16, 20), 2, MIXED_2D), (3, (16, 3, 20), 2, MIXED_3D), (2, (36, 5), 2, MIXED_2D)]   # (6 - 8 MFMA tiles per half line in x / y / z: the 6-, 7- and 8-wave transform workgroups with > 64 KB of LDS; the last three: DIFFERENT end conditions on lines of 33 / 41 / 73 points = an odd number of 16-point chunks in the full-length nodal kernels, whose fused last-direction pass wrote past a register array until round 3)   # (168 cells Q2: 336 / 337 modes per parity: the components differ in chunk count)
+         (2, (16, 20), 2, MIXED_2D), (3, (16, 3, 20), 2, MIXED_3D), (2, (36, 5), 2, MIXED_2D), (2, (170, 3), 2, MIXED_2D)]   # (the last: 341 points per line with different end conditions - planar form without the parity split)   # (6 - 8 MFMA tiles per half line in x / y / z: the 6-, 7- and 8-wave transform workgroups with > 64 KB of LDS; the last three: DIFFERENT end conditions on lines of 33 / 41 / 73 points = an odd number of 16-point chunks in the full-length nodal kernels, whose fused last-direction pass wrote past a register array until round 3)   # (168 cells Q2: 336 / 337 modes per parity: the components differ in chunk count)
 
 
 def block_inverse(A, mask, dim, g):
