@@ -256,8 +256,10 @@ template <int dim> class PoroElasticProblem {
   void initialize(const RunControls &rc) {
     displacement_solver.control.abs_tol = rc.abs_tol_u; displacement_solver.control.rel_tol = rc.rel_tol_u; displacement_solver.control.stop_rule = rc.stop_rule_u;
     displacement_solver.control.max_iter = pressure_solver.control.max_iter = strain_projector.control.max_iter = rc.max_iter;
-    displacement_solver.control.preconditioner = rc.preconditioner;
-    if (rc.preconditioner == PORO_PREC_CHEBYSHEV) { displacement_solver.control.omega = rc.chebyshev_ratio; displacement_solver.control.poly_degree = rc.chebyshev_degree; }
+    // rc.preconditioner < 0: the strongest displacement preconditioner this mesh supports
+    displacement_solver.control.preconditioner = rc.preconditioner >= 0 ? rc.preconditioner
+        : poro_supports_preconditioner(context(), 0, PORO_PREC_FDM) ? PORO_PREC_FDM : poro_supports_preconditioner(context(), 0, PORO_PREC_TWO_LEVEL) ? PORO_PREC_TWO_LEVEL : PORO_PREC_CHEBYSHEV;
+    if (displacement_solver.control.preconditioner == PORO_PREC_CHEBYSHEV) { displacement_solver.control.omega = rc.chebyshev_ratio; displacement_solver.control.poly_degree = rc.chebyshev_degree; }
     pressure_solver.control.preconditioner = strain_projector.control.preconditioner =
         rc.preconditioner == PORO_PREC_SSOR ? PORO_PREC_SSOR : rc.preconditioner_p >= 0 ? rc.preconditioner_p
         : poro_supports_preconditioner(context(), 1, PORO_PREC_FDM) ? PORO_PREC_FDM : PORO_PREC_JACOBI;

@@ -30,6 +30,8 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--ssor")) prec = PORO_PREC_SSOR;   // the reference's PreconditionSSOR instead of Jacobi
     else if (!std::strcmp(argv[i], "--chebyshev")) prec = PORO_PREC_CHEBYSHEV;   // polynomial preconditioner (any mesh / operator)
     else if (!std::strcmp(argv[i], "--block-fdm")) prec = PORO_PREC_FDM;         // block fast diagonalisation (uniform boxes with face-wise Dirichlet data)
+    else if (!std::strcmp(argv[i], "--two-level")) prec = PORO_PREC_TWO_LEVEL;   // Jacobi + block fast diagonalisation of the underlying / auxiliary box (refined boxes, rectangle-filling Gmsh meshes)
+    else if (!std::strcmp(argv[i], "--fastest")) prec = -1;                      // the strongest preconditioner the mesh supports: block FDM, else two-level, else Chebyshev
     else { std::cerr << "unknown option " << argv[i] << std::endl; return 1; }
   }
   try {
@@ -43,7 +45,7 @@ int main(int argc, char **argv) {
     P.bc.neumann_components.assign(data.stress_boundary_components.begin(), data.stress_boundary_components.end());
     P.bc.neumann_values = data.stress_boundary_values;
     P.mat = data.material();
-    if (!mesh_file.empty()) { P.mesh = read_gmsh22(mesh_file); P.finalize(degree); }
+    if (!mesh_file.empty()) { P.mesh = read_gmsh22(mesh_file); P.finalize(degree); attach_auxiliary_box(P, degree); }   // (coarse space of --two-level / --fastest where the mesh fills a rectangle)
     else {
       int n[3] = {1, 1, 1}; double size[3] = {1, 1, 1};
       for (int d = 0; d < data.dim; ++d) { n[d] = 1 << data.initial_refinement_level; size[d] = data.domain_size.at(d); }

@@ -47,6 +47,12 @@ def test_default_box_with_output_and_the_reference_preconditioner(tmp_path):
         assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(lc, [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", b)]))
     c = run(os.path.join(GOLDEN, "input.data"), "--steps", "1", "--matrix-free", "--mesh", os.path.join(GOLDEN, "domain.msh"), "--degree", "1", "--chebyshev")   # general matrix-free operator
     assert len(re.findall(r"pressure converged; iterations: (\d+)", c)) == 1
+    # read_mesh()'s grid with the strongest preconditioner it supports (--fastest -> the two-level form through the auxiliary box) and with --two-level by name: the same step
+    lim = [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", c)]
+    for flag in ("--fastest", "--two-level"):
+        e = run(os.path.join(GOLDEN, "input.data"), "--steps", "1", "--matrix-free", "--mesh", os.path.join(GOLDEN, "domain.msh"), "--degree", "1", flag)
+        le = [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", e)]
+        assert len(le) == len(lim) >= 1 and all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(le, lim))
     pa = re.findall(r"pressure converged; iterations: (\d+)", a); pb = re.findall(r"pressure converged; iterations: (\d+)", b)
     assert pa == pb and len(pa) == 2
     la = [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", a)]; lb = [float(m) for m in re.findall(r"Solution limits: ([0-9.eE+-]+)", b)]
