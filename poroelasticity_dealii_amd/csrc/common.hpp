@@ -249,6 +249,7 @@ void la_fill(hipStream_t s, double *x, double v, int64_t n);
 void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out);
 // z = omega D^-1 g + P z_c, zero on the inert dofs (additive two-level preconditioner)
 void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z);
+void la_copy_many(hipStream_t s, int count, double *const *dst, const double *const *src, const int64_t *n);   // several device-to-device copies in one launch
 void la_post(hipStream_t s, Mailbox *mb, unsigned long long seq, const double *src, int n, const PcgScalars *sc);
 void la_copy(hipStream_t s, double *y, const double *x, int64_t n);
 void la_axpy(hipStream_t s, double *y, double a, const double *x, int64_t n);

@@ -159,7 +159,9 @@ int poro_vec_norm(poro_ctx *c, int which, double *l2, double *linf) {
 int poro_state_save(poro_ctx *c) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
-    for (auto &kv : c->vec) { DevBuf<double> &d = c->vec_saved[kv.first]; if (d.n != kv.second.n) d.alloc(kv.second.n); la_copy(c->stream, d.p, kv.second.p, (int64_t)kv.second.n); }
+    std::vector<double *> dst; std::vector<const double *> src; std::vector<int64_t> len;
+    for (auto &kv : c->vec) { DevBuf<double> &d = c->vec_saved[kv.first]; if (d.n != kv.second.n) d.alloc(kv.second.n); dst.push_back(d.p); src.push_back(kv.second.p); len.push_back((int64_t)kv.second.n); }
+    la_copy_many(c->stream, (int)dst.size(), dst.data(), src.data(), len.data());
     PORO_HIP(hipStreamSynchronize(c->stream)); return 0;
   });
 }
@@ -167,7 +169,9 @@ int poro_state_restore(poro_ctx *c) {
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (c->vec_saved.empty()) throw Error("state_restore without state_save");
-    for (auto &kv : c->vec_saved) la_copy(c->stream, c->vec.at(kv.first).p, kv.second.p, (int64_t)kv.second.n);
+    std::vector<double *> dst; std::vector<const double *> src; std::vector<int64_t> len;
+    for (auto &kv : c->vec_saved) { dst.push_back(c->vec.at(kv.first).p); src.push_back(kv.second.p); len.push_back((int64_t)kv.second.n); }
+    la_copy_many(c->stream, (int)dst.size(), dst.data(), src.data(), len.data());      // (one launch instead of two dozen)
     // the solves that follow repeat earlier ones: forget the iteration-count history, so that a measurement of a repeated step cannot profit from a perfect prediction
     for (int *h : {c->pcg_hint_u, c->pcg_hint_fdm_u, c->pcg_hint_cheb_u}) h[0] = h[1] = 0;
     return 0;
