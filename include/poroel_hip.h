@@ -114,6 +114,10 @@ typedef struct poro_coarse_space {
   const int64_t *ptr;       /* [n_dofs_u / dim + 1] */
   const int32_t *node;      /* [ptr[last]] coarse node numbers */
   const double  *weight;
+  /* optional: the same for the pressure space (dof i = sum weight_p[k] * box pressure dof node_p[k]): PORO_PREC_TWO_LEVEL for the pressure and projection solves */
+  const int64_t *ptr_p;     /* [n_dofs_p + 1] or NULL */
+  const int32_t *node_p;
+  const double  *weight_p;
 } poro_coarse_space;
 
 /* Partition over ranks.  Slab form for a structured box:  The local mesh is
@@ -229,7 +233,9 @@ enum { PORO_STOP_RHS = 0, PORO_STOP_REDUCTION = 1 };
  * capped on uniform boxes by the rigorous element bound lambda_max(diag(K_e)^-1 K_e)).
  * PORO_PREC_TWO_LEVEL (displacement system; meshes with poro_desc.coarse, i.e. locally refined boxes with their hanging-node constraints) = additive two-level
  * preconditioner z = omega D^-1 g + P B_H^-1 P^T g: Jacobi on the refined mesh plus the BLOCK fast diagonalisation of the underlying uniform box as coarse solve (P = the
- * FE interpolation of poro_coarse_space).  The CG iteration count stays bounded under uniform refinement of the whole configuration. */
+ * FE interpolation of poro_coarse_space).  The CG iteration count stays bounded under uniform refinement of the whole configuration.  With poro_coarse_space.ptr_p ...
+ * also for poro_pres_solve (a M + kappa K: Jacobi + the box's exact scalar fast diagonalisation through the vertex interpolation; hanging nodes allowed, prescribed
+ * pressures not) and poro_proj_solve (accepted; Jacobi alone is already mesh-independent on the mass matrix and needs fewer iterations). */
 enum { PORO_PREC_NONE = 0, PORO_PREC_JACOBI = 1, PORO_PREC_SSOR = 2, PORO_PREC_FDM = 3, PORO_PREC_ILU0 = 4, PORO_PREC_CHEBYSHEV = 5, PORO_PREC_TWO_LEVEL = 6 };
 enum { PORO_OP_CSR = 0, PORO_OP_MATRIX_FREE = 1 };
 enum { PORO_MAT_A_U = 0, PORO_MAT_MASS_P = 1, PORO_MAT_LAPLACE_P = 2, PORO_MAT_JACOBIAN_P = 3 };

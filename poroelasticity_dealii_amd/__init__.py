@@ -54,7 +54,8 @@ class TensorGrid(C.Structure):
 
 
 class CoarseSpace(C.Structure):
-    _fields_ = [("enabled", C.c_int32), ("box_problem", C.c_void_p), ("ptr", C.POINTER(C.c_int64)), ("node", _ip), ("weight", _dp)]
+    _fields_ = [("enabled", C.c_int32), ("box_problem", C.c_void_p), ("ptr", C.POINTER(C.c_int64)), ("node", _ip), ("weight", _dp),
+                ("ptr_p", C.POINTER(C.c_int64)), ("node_p", _ip), ("weight_p", _dp)]
 
 
 class Desc(C.Structure):
@@ -505,13 +506,13 @@ def rccl_unique_id():
 
 
 def run_problem(problem, n_steps, p_init, dt, device=0, operator_mode=OP_CSR, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
-                abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False, cheb_degree=0, cheb_ratio=0):
+                abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False, cheb_degree=0, cheb_ratio=0, jacobi_p=False, two_level_p=False):
     """PoroElasticProblem<dim>::run() (PoroelasticityFSS.h:294-415) through the C++ host driver; returns (trace, Context)."""
     H = load_host()
     max_rows = 1 + n_steps * max_fss
     trace = np.zeros((max_rows, 8))
     ctx = C.c_void_p()
-    rows = H.poro_host_run(problem.handle, device, operator_mode, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0) | (int(cheb_degree) << 8) | (int(cheb_ratio) << 16),
+    rows = H.poro_host_run(problem.handle, device, operator_mode, p_init, dt, n_steps, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0) | (8 if jacobi_p else 0) | (16 if two_level_p else 0) | (int(cheb_degree) << 8) | (int(cheb_ratio) << 16),
                            trace.ctypes.data_as(_dp), max_rows, C.byref(ctx))
     if rows < 0:
         raise RuntimeError(H.poro_host_last_error().decode())
@@ -525,10 +526,10 @@ class Runner:
     """Steppable PoroElasticProblem<dim> (C++ host driver): initialize() = PoroelasticityFSS.h:308-317, step() = one pass of :328-407."""
 
     def __init__(self, problem, device=0, operator_mode=OP_MATRIX_FREE, p_init=10e6, dt=60.0, fss_tol=1e-8, pressure_tol=1e-8, max_fss=50, max_pres=50,
-                 abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False, cheb_degree=0, cheb_ratio=0):
+                 abs_u=1e-12, rel_u=0.0, max_it=1000, prec=PREC_JACOBI, coupled_fss=False, incremental_strain=False, reduction=False, cheb_degree=0, cheb_ratio=0, jacobi_p=False, two_level_p=False):
         self.H = load_host()
         self.max_fss = max_fss
-        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0) | (int(cheb_degree) << 8) | (int(cheb_ratio) << 16))
+        h = self.H.poro_host_runner_create(problem.handle, device, operator_mode, p_init, dt, fss_tol, pressure_tol, max_fss, max_pres, abs_u, rel_u, max_it, prec, int(bool(coupled_fss)) | (2 if incremental_strain else 0) | (4 if reduction else 0) | (8 if jacobi_p else 0) | (16 if two_level_p else 0) | (int(cheb_degree) << 8) | (int(cheb_ratio) << 16))
         if not h:
             raise RuntimeError(self.H.poro_host_last_error().decode())
         self.h = C.c_void_p(h)

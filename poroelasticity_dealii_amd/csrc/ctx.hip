@@ -293,7 +293,7 @@ int poro_disp_assemble_system(poro_ctx *c, int rebuild_matrix) {
 int poro_supports_preconditioner(poro_ctx *c, int32_t which_system, int32_t prec) {
   if (!c) return 0;
   if (prec == PORO_PREC_NONE || prec == PORO_PREC_JACOBI) return 1;
-  if (prec == PORO_PREC_TWO_LEVEL) return which_system == 0 && two_level_supported(c);
+  if (prec == PORO_PREC_TWO_LEVEL) return which_system == 0 ? two_level_supported(c) : (two_level_supported_p(c) && !c->n_pdir);
   if (which_system == 0 && c->cons_u.n) return prec == PORO_PREC_CHEBYSHEV;      // condensed operators exist at operator level only: Jacobi, the polynomial built on it, the two-level form above
   if (which_system == 1 && (c->cons_p.n || c->n_pdir)) return 0;
   if (prec == PORO_PREC_SSOR || prec == PORO_PREC_ILU0) return !c->comm.multi() && (which_system == 1 || c->operator_mode == PORO_OP_CSR);
@@ -540,7 +540,7 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
   return guarded([&] {
     PORO_HIP(hipSetDevice(c->device));
     if (c->jac_dt < 0) throw Error("pres_solve before pres_assemble_jacobian");
-    if ((c->cons_p.n || c->n_pdir) && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE) throw Error("meshes with hanging-node constraints or prescribed pressures: PORO_PREC_JACOBI / NONE only");
+    if ((c->cons_p.n || c->n_pdir) && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE && !(opts->preconditioner == PORO_PREC_TWO_LEVEL && !c->n_pdir)) throw Error("meshes with hanging-node constraints or prescribed pressures: PORO_PREC_JACOBI / NONE (hanging nodes: also TWO_LEVEL) only");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       return pcg_ilu0(c, c->Ap, c->Jp.p, c->ilu_J, c->ilu_J_valid, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     }
@@ -581,6 +581,16 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { fdm_precondition_p(c, ja, kk, g, z); return false; };
       DiagVec dz; dz.full = c->dinv_J.p; dz.z = c->wz_p.p;
       return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
+    }
+    if (opts->preconditioner == PORO_PREC_TWO_LEVEL) {
+      if (!two_level_supported_p(c)) throw Error("PORO_PREC_TWO_LEVEL (pressure): needs poro_desc.coarse with the pressure interpolation (ptr_p / node_p / weight_p)");
+      if (!c->wz_p.p) c->wz_p.alloc(c->n_p);
+      const double om = opts->omega > 0 ? opts->omega : 1.0;
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { two_level_precondition_p(c, ja, jk, c->dinv_J.p, g, z, om); return false; };
+      DiagVec dz; dz.full = c->dinv_J.p; dz.z = c->wz_p.p; dz.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
+      const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
+      la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_DP), true);
+      return rc;
     }
     DiagVec dv; dv.full = c->dinv_J.p; dv.inert = (c->cons_p.n || c->n_pdir) ? c->cons_p.inert.p : nullptr;
     const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
@@ -635,7 +645,7 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
     PORO_HIP(hipSetDevice(c->device));
     if (!c->projection_matrix_ready) throw Error("proj_solve before proj_assemble_matrix");
     if (entry < 0 || entry >= c->dim * (c->dim + 1) / 2) throw Error("rhs_entry out of range");
-    if (c->cons_p.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE) throw Error("meshes with hanging-node constraints: PORO_PREC_JACOBI / NONE only");
+    if (c->cons_p.n && opts->preconditioner != PORO_PREC_JACOBI && opts->preconditioner != PORO_PREC_NONE && opts->preconditioner != PORO_PREC_TWO_LEVEL) throw Error("meshes with hanging-node constraints: PORO_PREC_JACOBI / TWO_LEVEL / NONE only");
     if (opts->preconditioner == PORO_PREC_ILU0) {
       return pcg_ilu0(c, c->Ap, c->Mp.p, c->ilu_M, c->ilu_M_valid, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
     }
@@ -655,6 +665,16 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { fdm_precondition_p(c, 1.0, kk, g, z); return false; };
       DiagVec dz; dz.full = c->dinv_M.p; dz.z = c->wz_p.p;
       return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
+    }
+    if (opts->preconditioner == PORO_PREC_TWO_LEVEL) {
+      if (!two_level_supported_p(c)) throw Error("PORO_PREC_TWO_LEVEL (projection): needs poro_desc.coarse with the pressure interpolation");
+      if (!c->wz_p.p) c->wz_p.alloc(c->n_p);
+      const double om = opts->omega > 0 ? opts->omega : 1.0;
+      const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { two_level_precondition_p(c, 1.0, 0.0, c->dinv_M.p, g, z, om); return false; };
+      DiagVec dz; dz.full = c->dinv_M.p; dz.z = c->wz_p.p; dz.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
+      const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
+      la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_STRAIN0 + entry), true);
+      return rc;
     }
     DiagVec dv; dv.full = c->dinv_M.p; dv.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
     const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);

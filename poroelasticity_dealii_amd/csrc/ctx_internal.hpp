@@ -78,6 +78,8 @@ void build_fdm_p(poro_ctx *c);
 void alltoall_blocks(poro_ctx *c, double *send, double *recv, int64_t blk, bool self_in_place = false /* the caller has already put its own block into recv */);
 void setup_two_level(poro_ctx *c, const poro_desc *d);                // uploads P and its transpose (poro_desc.coarse)
 bool two_level_supported(poro_ctx *c);
+bool two_level_supported_p(poro_ctx *c);
+void two_level_precondition_p(poro_ctx *c, double a, double kappa, const double *dinv, const double *g, double *z, double omega);   // z = omega D^-1 g + P (a M_H + kappa K_H)^-1 P^T g
 void two_level_precondition_u(poro_ctx *c, const double *g, double *z, double omega);   // z = omega D^-1 g + P B_H^-1 P^T g
 void fdm_precondition_u_slab(poro_ctx *c, const double *g_quadrant, double *z_quadrant, const PcgScalars *gate);
 void fdm_precondition_p(poro_ctx *c, double a, const double k[3], const double *g, double *z);

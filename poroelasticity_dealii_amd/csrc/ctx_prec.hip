@@ -328,32 +328,53 @@ void fdm_precondition_u_slab(poro_ctx *c, const double *g, double *z, const PcgS
   fdmo_slab_pass(s, O, 3, S.buf.p, z, gate);                                          // y, x backward, reading the received planes in place
 }
 // ---- additive two-level preconditioner on refinements of a uniform box (poro_desc.coarse) ----------------------------------------------------
+static void upload_interp(poro_ctx::Interp &T, int64_t n_fine, int64_t n_coarse, const int64_t *ptr, const int32_t *node, const double *weight, const char *what) {
+  T.n_fine = n_fine; T.n_coarse = n_coarse;
+  const int64_t nnz = ptr[n_fine];
+  T.long_rows_t = nnz >= 4 * n_coarse;                                          // restriction rows of several entries on average: a lane group per row
+  std::vector<int64_t> tp((size_t)n_coarse + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) { const int32_t j = node[k]; if (j < 0 || j >= n_coarse) throw Error(std::string("poro_desc.coarse: ") + what + " node out of range"); tp[j + 1]++; }
+  for (int64_t j = 0; j < n_coarse; ++j) tp[j + 1] += tp[j];
+  std::vector<int32_t> tc((size_t)nnz); std::vector<double> tw((size_t)nnz); std::vector<int64_t> pos(tp.begin(), tp.end() - 1);
+  for (int64_t i = 0; i < n_fine; ++i) {
+    if (ptr[i + 1] < ptr[i]) throw Error("poro_desc.coarse: ptr not monotone");
+    for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) { const int64_t at = pos[node[k]]++; tc[at] = (int32_t)i; tw[at] = weight[k]; }
+  }
+  T.p_ptr.upload(ptr, (size_t)n_fine + 1); T.p_col.upload(node, (size_t)nnz); T.p_w.upload(weight, (size_t)nnz);
+  T.pt_ptr.upload(tp); T.pt_col.upload(tc); T.pt_w.upload(tw);
+}
 void setup_two_level(poro_ctx *c, const poro_desc *d) {
   auto &T = c->two_level; const int dim = c->dim;
-  T.n_fine = c->n_u / dim; T.n_coarse = T.box->n_u / dim;
-  const int64_t nnz = d->coarse.ptr[T.n_fine];
-  std::vector<int64_t> tp((size_t)T.n_coarse + 1, 0);
-  for (int64_t k = 0; k < nnz; ++k) { const int32_t j = d->coarse.node[k]; if (j < 0 || j >= T.n_coarse) throw Error("poro_desc.coarse.node out of range"); tp[j + 1]++; }
-  for (int64_t j = 0; j < T.n_coarse; ++j) tp[j + 1] += tp[j];
-  std::vector<int32_t> tc((size_t)nnz); std::vector<double> tw((size_t)nnz); std::vector<int64_t> pos(tp.begin(), tp.end() - 1);
-  for (int64_t i = 0; i < T.n_fine; ++i) {
-    if (d->coarse.ptr[i + 1] < d->coarse.ptr[i]) throw Error("poro_desc.coarse.ptr not monotone");
-    for (int64_t k = d->coarse.ptr[i]; k < d->coarse.ptr[i + 1]; ++k) { const int64_t at = pos[d->coarse.node[k]]++; tc[at] = (int32_t)i; tw[at] = d->coarse.weight[k]; }
+  upload_interp(T, c->n_u / dim, T.box->n_u / dim, d->coarse.ptr, d->coarse.node, d->coarse.weight, "displacement");
+  if (d->coarse.ptr_p) {
+    if (!d->coarse.node_p || !d->coarse.weight_p) throw Error("poro_desc.coarse: node_p / weight_p missing");
+    upload_interp(T.pressure, c->n_p, T.box->n_p, d->coarse.ptr_p, d->coarse.node_p, d->coarse.weight_p, "pressure");
   }
-  T.p_ptr.upload(d->coarse.ptr, (size_t)T.n_fine + 1); T.p_col.upload(d->coarse.node, (size_t)nnz); T.p_w.upload(d->coarse.weight, (size_t)nnz);
-  T.pt_ptr.upload(tp); T.pt_col.upload(tc); T.pt_w.upload(tw);
 }
 bool two_level_supported(poro_ctx *c) {
   if (!c->two_level.box) return false;
   analyse_fdm_u(c->two_level.box);
   return c->two_level.box->fdm_u_state == 1;
 }
+bool two_level_supported_p(poro_ctx *c) { return c->two_level.box && c->two_level.pressure.n_fine == c->n_p && fdm_p_supported(c->two_level.box); }
+// the scalar analogue for the pressure Jacobian a M + kappa K and the projection mass matrix (a = 1, kappa = 0): Jacobi on this mesh + the box's exact fast diagonalisation
+void two_level_precondition_p(poro_ctx *c, double a, double kappa, const double *dinv, const double *g, double *z, double omega) {
+  Timed tm(c, "precondition_p_two_level");
+  auto &T = c->two_level.pressure; poro_ctx *H = c->two_level.box; hipStream_t s = c->stream;
+  build_fdm_p(H);
+  if (!H->wz_p.p) H->wz_p.alloc(H->n_p);
+  double *rc = H->wg_p.p, *zc = H->wz_p.p;
+  la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, 1, g, rc, T.long_rows_t);
+  const double kk[3] = {kappa, kappa, kappa};
+  fdm_precondition_p(H, a, kk, rc, zc);
+  la_two_level_combine(s, T.p_ptr.p, T.p_col.p, T.p_w.p, T.n_fine, 1, zc, g, dinv, (c->cons_p.n || c->n_pdir) ? c->cons_p.inert.p : nullptr, omega, z);
+}
 void two_level_precondition_u(poro_ctx *c, const double *g, double *z, double omega) {
   Timed tm(c, "precondition_u_two_level");
   auto &T = c->two_level; poro_ctx *H = T.box; hipStream_t s = c->stream; const int dim = c->dim;
   build_fdm_u(H);
   double *rc = H->wg_u.p, *zc = H->wz_u.p;                                  // the box context's work vectors (it never solves anything itself)
-  la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, dim, g, rc);              // r_H = P^T g
+  la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, dim, g, rc, T.long_rows_t);              // r_H = P^T g
   FdmOct &O = H->fdm_oct;
   if (O.built) { fdmo_from_nodal(s, O, rc, O.g.p); if (O.planar) fdmo_apply_planar(s, O, O.g.p, O.z.p); else fdmo_apply(s, O, O.g.p, O.z.p, O.t.p); fdmo_to_nodal(s, O, O.z.p, zc); }
   else fdm_precondition_u(H, rc, zc);                                         // z_H = blockdiag(A_H)^-1 r_H (zero on the box's Dirichlet faces)

@@ -392,8 +392,28 @@ __global__ void __launch_bounds__(kBlock) k_nodal_interp(const int64_t *__restri
     out[t] = acc;
   }
 }
-void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out) {
-  if (n_rows) hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, (const double *)nullptr, (const double *)nullptr, (const uint8_t *)nullptr, 0.0);
+// long rows (the restriction P^T of a refined block: up to (4k - 1)^dim entries per coarse node next to single-entry rows): LANES consecutive lanes share a row,
+// consecutive entries to consecutive lanes, partial sums folded with DPP-width shuffles
+template <int LANES>
+__global__ void __launch_bounds__(kBlock) k_nodal_interp_wide(const int64_t *__restrict__ ptr, const int32_t *__restrict__ col, const double *__restrict__ w, int64_t n_rows, int ncomp, const double *__restrict__ in, double *__restrict__ out) {
+  const int lane = threadIdx.x % LANES;
+  const int64_t total = n_rows * ncomp, per_pass = (int64_t)gridDim.x * (kBlock / LANES);
+  const int64_t last = ((total + per_pass - 1) / per_pass) * per_pass;          // whole groups stay in the loop together (the shuffles need every lane)
+  for (int64_t t = (int64_t)blockIdx.x * (kBlock / LANES) + threadIdx.x / LANES; t < last; t += per_pass) {
+    double acc = 0;
+    if (t < total) {
+      const int64_t row = t / ncomp; const int c = (int)(t - row * ncomp);
+      for (int64_t k = ptr[row] + lane; k < ptr[row + 1]; k += LANES) acc = fma(w[k], in[(int64_t)col[k] * ncomp + c], acc);
+    }
+#pragma unroll
+    for (int m = LANES / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, LANES);
+    if (lane == 0 && t < total) out[t] = acc;
+  }
+}
+void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, bool long_rows) {
+  if (!n_rows) return;
+  if (long_rows) { constexpr int L = 8; hipLaunchKernelGGL(k_nodal_interp_wide<L>, grid_for(n_rows * ncomp * L), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out); return; }
+  hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, (const double *)nullptr, (const double *)nullptr, (const uint8_t *)nullptr, 0.0);
 }
 void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z) {
   if (n_rows) hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, zc, z, g, dinv, inert, omega);

@@ -171,11 +171,11 @@ int poro_host_read_input(const char *path /* NULL = declared defaults */, poro_i
 // PoroElasticProblem<dim>::run() on the HIP back end (problem.hpp).  trace rows: see PoroElasticProblem::time_step.
 int poro_host_run(void *problem_data, int device, int operator_mode, double p_init, double dt, int n_steps,
                   double fss_tol, double pressure_tol, int max_fss, int max_pres,
-                  double abs_u, double rel_u, int max_it, int preconditioner, int flags /* bit 0: coupled_fss, bit 1: incremental_strain, bit 2: PORO_STOP_REDUCTION for the displacement solve, bits 8-15: Chebyshev degree, bits 16-30: Chebyshev interval ratio (0 = defaults) */, double *trace, int max_rows, poro_ctx **ctx_out) {
+                  double abs_u, double rel_u, int max_it, int preconditioner, int flags /* bit 0: coupled_fss, bit 1: incremental_strain, bit 2: PORO_STOP_REDUCTION for the displacement solve, bit 3: Jacobi for the pressure / projection solves (default: the strongest form the mesh supports), bit 4: PORO_PREC_TWO_LEVEL for them, bits 8-15: Chebyshev degree, bits 16-30: Chebyshev interval ratio (0 = defaults) */, double *trace, int max_rows, poro_ctx **ctx_out) {
   try {
     auto *P = static_cast<ProblemData *>(problem_data);
     RunControls rc; rc.p_init = p_init; rc.time_step = dt; rc.n_steps = n_steps; rc.fss_tol = fss_tol; rc.pressure_tol = pressure_tol;
-    rc.max_fss_iterations = max_fss; rc.max_pressure_iterations = max_pres; rc.abs_tol_u = abs_u; rc.rel_tol_u = rel_u; rc.max_iter = max_it; rc.preconditioner = preconditioner; rc.coupled_fss = (flags & 1) != 0; rc.incremental_strain = (flags & 2) != 0; rc.stop_rule_u = (flags & 4) ? PORO_STOP_REDUCTION : PORO_STOP_RHS; rc.chebyshev_degree = (flags >> 8) & 0xff; rc.chebyshev_ratio = (double)((flags >> 16) & 0x7fff);
+    rc.max_fss_iterations = max_fss; rc.max_pressure_iterations = max_pres; rc.abs_tol_u = abs_u; rc.rel_tol_u = rel_u; rc.max_iter = max_it; rc.preconditioner = preconditioner; rc.coupled_fss = (flags & 1) != 0; rc.incremental_strain = (flags & 2) != 0; rc.stop_rule_u = (flags & 4) ? PORO_STOP_REDUCTION : PORO_STOP_RHS; if (flags & 8) rc.preconditioner_p = PORO_PREC_JACOBI; if (flags & 16) rc.preconditioner_p = PORO_PREC_TWO_LEVEL; rc.chebyshev_degree = (flags >> 8) & 0xff; rc.chebyshev_ratio = (double)((flags >> 16) & 0x7fff);
     int rows = 0;
     if (P->mesh.dim == 2) { PoroElasticProblem<2> prob(*P, device, operator_mode); rows = prob.run(rc, trace, max_rows); if (ctx_out) *ctx_out = prob.release(); }
     else { PoroElasticProblem<3> prob(*P, device, operator_mode); rows = prob.run(rc, trace, max_rows); if (ctx_out) *ctx_out = prob.release(); }
@@ -189,12 +189,12 @@ struct HostRunner {
   ~HostRunner() { delete p2; delete p3; }
 };
 void *poro_host_runner_create(void *problem_data, int device, int operator_mode, double p_init, double dt, double fss_tol, double pressure_tol,
-                              int max_fss, int max_pres, double abs_u, double rel_u, int max_it, int preconditioner, int flags /* bit 0: coupled_fss, bit 1: incremental_strain, bit 2: PORO_STOP_REDUCTION for the displacement solve, bits 8-15: Chebyshev degree, bits 16-30: Chebyshev interval ratio (0 = defaults) */) {
+                              int max_fss, int max_pres, double abs_u, double rel_u, int max_it, int preconditioner, int flags /* bit 0: coupled_fss, bit 1: incremental_strain, bit 2: PORO_STOP_REDUCTION for the displacement solve, bit 3: Jacobi for the pressure / projection solves (default: the strongest form the mesh supports), bit 4: PORO_PREC_TWO_LEVEL for them, bits 8-15: Chebyshev degree, bits 16-30: Chebyshev interval ratio (0 = defaults) */) {
   try {
     auto *P = static_cast<ProblemData *>(problem_data);
     auto *R = new HostRunner(); R->dim = P->mesh.dim;
     R->rc.p_init = p_init; R->rc.time_step = dt; R->rc.fss_tol = fss_tol; R->rc.pressure_tol = pressure_tol; R->rc.max_fss_iterations = max_fss;
-    R->rc.max_pressure_iterations = max_pres; R->rc.abs_tol_u = abs_u; R->rc.rel_tol_u = rel_u; R->rc.max_iter = max_it; R->rc.preconditioner = preconditioner; R->rc.coupled_fss = (flags & 1) != 0; R->rc.incremental_strain = (flags & 2) != 0; R->rc.stop_rule_u = (flags & 4) ? PORO_STOP_REDUCTION : PORO_STOP_RHS; R->rc.chebyshev_degree = (flags >> 8) & 0xff; R->rc.chebyshev_ratio = (double)((flags >> 16) & 0x7fff);
+    R->rc.max_pressure_iterations = max_pres; R->rc.abs_tol_u = abs_u; R->rc.rel_tol_u = rel_u; R->rc.max_iter = max_it; R->rc.preconditioner = preconditioner; R->rc.coupled_fss = (flags & 1) != 0; R->rc.incremental_strain = (flags & 2) != 0; R->rc.stop_rule_u = (flags & 4) ? PORO_STOP_REDUCTION : PORO_STOP_RHS; if (flags & 8) R->rc.preconditioner_p = PORO_PREC_JACOBI; if (flags & 16) R->rc.preconditioner_p = PORO_PREC_TWO_LEVEL; R->rc.chebyshev_degree = (flags >> 8) & 0xff; R->rc.chebyshev_ratio = (double)((flags >> 16) & 0x7fff);
     if (R->dim == 2) R->p2 = new PoroElasticProblem<2>(*P, device, operator_mode); else R->p3 = new PoroElasticProblem<3>(*P, device, operator_mode);
     return R;
   } catch (const std::exception &e) { g_err = e.what(); return nullptr; }

@@ -261,6 +261,7 @@ struct RefinedBox {
   Mesh mesh; DoFs dofs; ConstraintList cons_u, cons_p;
   // interpolation from the underlying uniform box: displacement node i = sum of weight * box node (lexicographic box numbering), rows by prol_ptr
   std::vector<int64_t> prol_ptr; std::vector<int32_t> prol_node; std::vector<double> prol_w;
+  std::vector<int64_t> prol_ptr_p; std::vector<int32_t> prol_node_p; std::vector<double> prol_w_p;     // the same for the pressure space (vertices)
 };
 inline RefinedBox make_refined_box(int dim, const int n[3], const double origin[3], const double h[3], int k_u, const int lo[3], const int hi[3]) {
   RefinedBox R; Mesh &m = R.mesh; m.dim = dim;
@@ -360,6 +361,20 @@ inline RefinedBox make_refined_box(int dim, const int n[3], const double origin[
       }
       R.prol_ptr.push_back((int64_t)R.prol_node.size());
     }
+    // pressure space: vertices, lattice units h / 2, box vertices lexicographic
+    const int nsp = 1 << dim; const int64_t np0 = (int64_t)nc[0] + 1, np1 = (int64_t)nc[1] + 1;
+    std::vector<double> valp(nsp), gradp((size_t)nsp * dim);
+    R.prol_ptr_p.assign(1, 0);
+    for (size_t nd = 0; nd < cp.size(); ++nd) {
+      int c[3] = {0, 0, 0}; double xi[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) { c[d] = std::min(cp[nd][d] / 2, nc[d] - 1); xi[d] = (double)(cp[nd][d] - 2 * c[d]) / 2; }
+      shape_at(dim, 1, xi, valp.data(), gradp.data());
+      for (int s = 0; s < nsp; ++s) if (std::fabs(valp[s]) > 1e-13) {
+        const int a[3] = {s & 1, (s >> 1) & 1, s >> 2};
+        R.prol_node_p.push_back((int32_t)(((int64_t)(dim == 3 ? c[2] + a[2] : 0) * np1 + (c[1] + a[1])) * np0 + (c[0] + a[0]))); R.prol_w_p.push_back(valp[s]);
+      }
+      R.prol_ptr_p.push_back((int64_t)R.prol_node_p.size());
+    }
   }
   return R;
 }
@@ -393,6 +408,7 @@ struct ProblemData {
   std::vector<double> tensor_grid[3]; // vertex planes per direction of a tensor-product grid without the box tag (graded boxes)
   // locally refined boxes: the underlying uniform box as a problem of its own + the interpolation from it (poro_coarse_space)
   std::unique_ptr<ProblemData> coarse; std::vector<int64_t> prol_ptr; std::vector<int32_t> prol_node; std::vector<double> prol_w;
+  std::vector<int64_t> prol_ptr_p; std::vector<int32_t> prol_node_p; std::vector<double> prol_w_p;
   poro_desc d{};
 
   // ConstraintMatrix semantics of PoroElasticDisplacementSolver.h:112-136: hanging-node constraints first, boundary values only for dofs that are
@@ -550,8 +566,19 @@ inline bool attach_auxiliary_box(ProblemData &P, int k_u) {
     }
     P.prol_ptr.push_back((int64_t)P.prol_node.size());
   }
+  // pressure space: the mesh's vertices in the box's Q1 space
+  { const int64_t np0 = (int64_t)n[0] + 1; double v4[4], g8[8];
+    P.prol_ptr_p.assign(1, 0); P.prol_node_p.clear(); P.prol_w_p.clear();
+    for (int64_t v = 0; v < m.n_vertices(); ++v) {
+      int c[2]; double xi[2];
+      for (int d = 0; d < 2; ++d) { const double t = (m.vertices[2 * v + d] - origin[d]) / h[d]; c[d] = std::min(std::max((int)std::floor(t), 0), n[d] - 1); xi[d] = std::min(std::max(t - c[d], 0.0), 1.0); }
+      shape_at(dim, 1, xi, v4, g8);
+      for (int s = 0; s < 4; ++s) if (std::fabs(v4[s]) > 1e-13) { P.prol_node_p.push_back((int32_t)((int64_t)(c[1] + (s >> 1)) * np0 + (c[0] + (s & 1)))); P.prol_w_p.push_back(v4[s]); }
+      P.prol_ptr_p.push_back((int64_t)P.prol_node_p.size());
+    } }
   P.d.coarse = poro_coarse_space{}; P.d.coarse.enabled = 1; P.d.coarse.box_problem = &C.d;
   P.d.coarse.ptr = P.prol_ptr.data(); P.d.coarse.node = P.prol_node.data(); P.d.coarse.weight = P.prol_w.data();
+  P.d.coarse.ptr_p = P.prol_ptr_p.data(); P.d.coarse.node_p = P.prol_node_p.data(); P.d.coarse.weight_p = P.prol_w_p.data();
   return true;
 }
 
@@ -586,6 +613,7 @@ inline void build_refined_box_problem(ProblemData &P, int dim, const int n[3], c
   RefinedBox R = make_refined_box(dim, n, origin, h, k_u, lo, hi);
   P.mesh = std::move(R.mesh); P.dofs = std::move(R.dofs); P.cons_u = std::move(R.cons_u); P.cons_p = std::move(R.cons_p);
   P.prol_ptr = std::move(R.prol_ptr); P.prol_node = std::move(R.prol_node); P.prol_w = std::move(R.prol_w);
+  P.prol_ptr_p = std::move(R.prol_ptr_p); P.prol_node_p = std::move(R.prol_node_p); P.prol_w_p = std::move(R.prol_w_p);
   P.part = poro_partition{}; P.part.n_ranks = 1;
   P.finalize(k_u, true);
   // coarse space of the two-level preconditioner: the unrefined box with the same material and boundary conditions
@@ -593,6 +621,7 @@ inline void build_refined_box_problem(ProblemData &P, int dim, const int n[3], c
   build_box_problem(*P.coarse, dim, n, size, k_u);
   P.d.coarse = poro_coarse_space{}; P.d.coarse.enabled = 1; P.d.coarse.box_problem = &P.coarse->d;
   P.d.coarse.ptr = P.prol_ptr.data(); P.d.coarse.node = P.prol_node.data(); P.d.coarse.weight = P.prol_w.data();
+  P.d.coarse.ptr_p = P.prol_ptr_p.data(); P.d.coarse.node_p = P.prol_node_p.data(); P.d.coarse.weight_p = P.prol_w_p.data();
 }
 
 // ---- general partition (last sentence): contiguous ranges of the cells in Morton order + indexed interface lists --------------

@@ -50,7 +50,7 @@ struct RunControls {
   bool corrected_postprocessing = false;                            // false = the reference's output (shear RHS never assembled, 2D "sigma_yy" shows sigma_xx); true = both fixed
   std::string output_dir;                                           // "" = no files; the reference always writes ./solution/solution-NNNN.vtk (:285-290)
   int chebyshev_degree = 0; double chebyshev_ratio = 0.0;           // PORO_PREC_CHEBYSHEV: 0 = the library's defaults
-  int preconditioner_p = -1;                                        // pressure / projection solves; -1 = fast diagonalisation where the context supports it, else Jacobi
+  int preconditioner_p = -1;                                        // pressure / projection solves; -1 = fast diagonalisation where the context supports it, else the two-level form, else Jacobi
 };
 
 }  // namespace poro_host
@@ -263,6 +263,11 @@ template <int dim> class PoroElasticProblem {
     pressure_solver.control.preconditioner = strain_projector.control.preconditioner =
         rc.preconditioner == PORO_PREC_SSOR ? PORO_PREC_SSOR : rc.preconditioner_p >= 0 ? rc.preconditioner_p
         : poro_supports_preconditioner(context(), 1, PORO_PREC_FDM) ? PORO_PREC_FDM : PORO_PREC_JACOBI;
+    // the pressure Jacobian's stiffness part makes Jacobi-CG grow with 1/h: the two-level form where the mesh carries a coarse space.  (The projection's mass matrix
+    // is well conditioned under Jacobi on any mesh: 12-15 iterations, fewer than the additive two-level form needs; below ~8k pressure dofs a CG iteration is
+    // launch-bound and the two-level form's extra launches cost more than the iterations it saves - profiles/r03_refined_box_step.json.)
+    if (rc.preconditioner != PORO_PREC_SSOR && rc.preconditioner_p < 0 && pressure_solver.control.preconditioner == PORO_PREC_JACOBI && pd->d.n_dofs_p >= 8192 && poro_supports_preconditioner(context(), 1, PORO_PREC_TWO_LEVEL))
+      pressure_solver.control.preconditioner = PORO_PREC_TWO_LEVEL;
     setup_dofs();                                          // :308
     pressure_solver.solution = rc.p_init;                  // :311
     check(poro_pres_apply_boundary_values(ctx), "pres_apply_boundary_values");   // (extension: prescribed pressures; no-op for the reference's problems)

@@ -151,5 +151,15 @@ def test_coarse_space_of_a_refined_box_interpolates_polynomials(dim, n, deg, lo,
             for a in range(dim):
                 for b in range(a, dim):
                     assert np.abs(Pm @ (Xc[:, a] * Xc[:, b]) - Xf[:, a] * Xf[:, b]).max() <= 1e-11
+        # the pressure space (Q1 on the vertices): ptr_p / node_p / weight_p interpolate the box's vertex functions; at most 2^dim entries per row
+        npf = d.n_dofs_p; npc = box.n_dofs_p
+        ptr = np.ctypeslib.as_array(d.coarse.ptr_p, shape=(npf + 1,)); nnz = int(ptr[-1])
+        node = np.ctypeslib.as_array(d.coarse.node_p, shape=(nnz,)); w = np.ctypeslib.as_array(d.coarse.weight_p, shape=(nnz,))
+        assert ptr[0] == 0 and np.all(np.diff(ptr) >= 1) and np.all(np.diff(ptr) <= 2 ** dim) and node.min() >= 0 and node.max() < npc and w.min() > 0
+        Pp = sp.csr_matrix((w, node, ptr), shape=(npf, npc))
+        Xp = np.ctypeslib.as_array(d.vertex_coords, shape=(d.n_vertices, dim))
+        grids = np.meshgrid(*[np.linspace(-5.0, 5.0, n[a] + 1) for a in range(dim)], indexing="ij")
+        Xv = np.stack([g.transpose(*reversed(range(dim))).ravel() for g in grids], axis=1)
+        assert np.abs(Pp @ np.ones(npc) - 1.0).max() <= 1e-13 and np.abs(Pp @ Xv - Xp).max() <= 1e-12
     finally:
         P.close()

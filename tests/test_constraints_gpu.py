@@ -89,6 +89,16 @@ def test_condensed_pressure_and_projection_systems(trio):
         assert rel2(G.get(pk.VEC_PROJ_RHS0 + e), O.get(pk.VEC_PROJ_RHS0 + e)) <= 1e-12
         rc0, _ = O.proj_solve(e, rel_tol=1e-13, max_iter=5000); rc1, _ = G.proj_solve(e, rel_tol=1e-13, max_iter=5000)
         assert rc0 == 0 and rc1 == 0 and rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
+    # the two-level form of the scalar systems (Jacobi here + the underlying box's exact fast diagonalisation through the vertex interpolation poro_desc.coarse.ptr_p ...):
+    # the same condensed solutions, hanging values distributed
+    assert G.supports_preconditioner(1, pk.PREC_TWO_LEVEL)
+    G.fill(pk.VEC_DP, 0.0)
+    rc2, two = G.pres_solve(rel_tol=1e-13, max_iter=500, prec=pk.PREC_TWO_LEVEL)
+    assert rc2 == 0 and two.iterations > 0 and rel2(G.get(pk.VEC_DP), O.get(pk.VEC_DP)) <= 1e-9
+    for e in ([0, 2] if G.dim == 2 else [0, 3, 5]):
+        G.fill(pk.VEC_STRAIN0 + e, 0.0)
+        rc2, two = G.proj_solve(e, rel_tol=1e-13, max_iter=500, prec=pk.PREC_TWO_LEVEL)
+        assert rc2 == 0 and two.iterations > 0 and rel2(G.get(pk.VEC_STRAIN0 + e), O.get(pk.VEC_STRAIN0 + e)) <= 1e-9
 
 
 @pytest.mark.parametrize("cfg", MESHES[1:3], ids=str)
@@ -130,7 +140,7 @@ def test_two_level_preconditioner_on_refined_boxes(trio):
     """PORO_PREC_TWO_LEVEL: Jacobi on the refined mesh + block fast diagonalisation of the underlying uniform box (poro_desc.coarse, interpolation P) - the same
     condensed solution as the oracle's Jacobi-CG, in far fewer iterations"""
     P, O, G = trio
-    assert P.desc.coarse.enabled and G.supports_preconditioner(0, pk.PREC_TWO_LEVEL) and not G.supports_preconditioner(1, pk.PREC_TWO_LEVEL)
+    assert P.desc.coarse.enabled and G.supports_preconditioner(0, pk.PREC_TWO_LEVEL) and G.supports_preconditioner(1, pk.PREC_TWO_LEVEL)
     p = REF["p_init"] * (1 + 0.3 * np.sin(0.37 * np.arange(G.n_p)))
     for S in (O, G):
         S.set(pk.VEC_P, p); S.disp_assemble_system(True)
@@ -166,3 +176,52 @@ def test_two_level_iteration_counts_do_not_grow_with_refinement():
     print("two-level CG iterations per refinement:", counts, "Jacobi:", jacobi)
     assert counts[1] <= 1.3 * counts[0] and counts[2] <= 1.3 * counts[1], counts
     assert counts[1] < jacobi[1] / 3, (counts, jacobi)
+
+
+def test_two_level_scalar_solves_do_not_grow_with_refinement():
+    """pressure Jacobian (dt = 60 s: the stiffness part dominates) and projection mass matrix on uniformly refined configurations: the two-level CG counts stay flat,
+    Jacobi's pressure count roughly doubles per level"""
+    from common import BC_3D, material
+    pres, proj, jac = [], [], []
+    for n in (4, 8, 16):
+        P = pk.Problem.refined_box(3, [n] * 3, [10.0] * 3, 2, material(), BC_3D, [n // 4] * 3, [3 * n // 4] * 3)
+        G = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+        try:
+            m = G.n_p
+            vals = {pk.VEC_P: 10e6 * (1 + 0.05 * np.sin(0.37 * np.arange(m))), pk.VEC_P_OLD: 10e6 * (1 + 0.05 * np.sin(0.2 * np.arange(m))),
+                    pk.VEC_EPSV: -2e-6 * (1 + 0.3 * np.sin(0.5 * np.arange(m))), pk.VEC_EPSV0: -2e-6 * np.ones(m)}
+            for k, v in vals.items():
+                G.set(k, v)
+            G.pres_assemble_residual(60.0); G.pres_assemble_jacobian(60.0)
+            rc, info = G.pres_solve(rel_tol=1e-8, max_iter=500, prec=pk.PREC_TWO_LEVEL)
+            assert rc == 0
+            pres.append(info.iterations); dp = G.get(pk.VEC_DP)
+            G.fill(pk.VEC_DP, 0.0)
+            rc, info = G.pres_solve(rel_tol=1e-8, max_iter=20000)
+            assert rc == 0 and rel2(dp, G.get(pk.VEC_DP)) <= 1e-6
+            jac.append(info.iterations)
+            G.set(pk.VEC_U, 1e-5 * np.sin(0.05 * np.arange(G.n_u)))
+            G.proj_assemble_matrix(); G.proj_assemble_rhs([0])
+            rc, info = G.proj_solve(0, rel_tol=1e-8, max_iter=500, prec=pk.PREC_TWO_LEVEL)
+            assert rc == 0
+            proj.append(info.iterations)
+        finally:
+            G.close(); P.close()
+    print("two-level CG iterations, pressure:", pres, "projection:", proj, "Jacobi pressure:", jac)
+    assert pres[2] <= 1.3 * pres[1] and proj[2] <= 1.3 * proj[1], (pres, proj)
+    assert pres[2] < jac[2] / 3, (pres, jac)
+
+
+def test_time_steps_with_the_two_level_solvers_track_the_oracle():
+    """the whole fixed-stress loop with PORO_PREC_TWO_LEVEL on all three systems (the driver's own choice on a mesh this small would be Jacobi for the scalar ones): the same FSS / pressure iteration structure and fields as the oracle's Jacobi-CG run"""
+    P = refined(3, (3, 3, 2), 2, (1, 1, 0), (2, 2, 1))
+    O = oracle_py.Oracle(P, hoisted=True)
+    try:
+        t0, _ = O.run(2, REF["p_init"], REF["dt"], max_it=20000, prec=oracle_py.PREC_JACOBI)
+        t1, G = pk.run_problem(P, 2, REF["p_init"], REF["dt"], operator_mode=pk.OP_MATRIX_FREE, max_it=2000, prec=pk.PREC_TWO_LEVEL, two_level_p=True)
+        assert np.array_equal(t1[:, :3], t0[:, :3])
+        assert rel2(G.get(pk.VEC_U), O.get(pk.VEC_U)) <= 1e-7
+        assert np.abs(G.get(pk.VEC_P) - O.get(pk.VEC_P)).max() <= 1e-9 * np.abs(O.get(pk.VEC_P)).max()
+        G.close()
+    finally:
+        O.close(); P.close()
