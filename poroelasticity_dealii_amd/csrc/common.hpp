@@ -235,6 +235,7 @@ struct poro_ctx {
   int interleaved_u = 0;
   int pcg_hint_fdm_u[2] = {0, 0}, pcg_hint_cheb_u[2] = {0, 0}; int64_t cheb_applies = 0;
   int pcg_hint_u[2] = {0, 0};   // iterations of the last two displacement solves (batch scheduling of the next one)
+  int pcg_hint_p[2] = {0, 0}, pcg_hint_proj[2] = {0, 0};   // the same for the iterative pressure / projection solves
   int n_cus = 256; int mf_variant = 1 /* 0 element-matrix gather, 1 sum-factorised (where supported) */; int mask_anywhere = 0;
   // timing
   bool timing = false; std::map<std::string, poro::Timer> timers; std::vector<hipEvent_t> event_pool;

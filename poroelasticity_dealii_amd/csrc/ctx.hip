@@ -173,7 +173,7 @@ int poro_state_restore(poro_ctx *c) {
     for (auto &kv : c->vec_saved) { dst.push_back(c->vec.at(kv.first).p); src.push_back(kv.second.p); len.push_back((int64_t)kv.second.n); }
     la_copy_many(c->stream, (int)dst.size(), dst.data(), src.data(), len.data());      // (one launch instead of two dozen)
     // the solves that follow repeat earlier ones: forget the iteration-count history, so that a measurement of a repeated step cannot profit from a perfect prediction
-    for (int *h : {c->pcg_hint_u, c->pcg_hint_fdm_u, c->pcg_hint_cheb_u}) h[0] = h[1] = 0;
+    for (int *h : {c->pcg_hint_u, c->pcg_hint_fdm_u, c->pcg_hint_cheb_u, c->pcg_hint_p, c->pcg_hint_proj}) h[0] = h[1] = 0;
     return 0;
   });
 }
@@ -580,7 +580,7 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       }
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { fdm_precondition_p(c, ja, kk, g, z); return false; };
       DiagVec dz; dz.full = c->dinv_J.p; dz.z = c->wz_p.p;
-      return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
+      return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P, c->pcg_hint_p);
     }
     if (opts->preconditioner == PORO_PREC_TWO_LEVEL) {
       if (!two_level_supported_p(c)) throw Error("PORO_PREC_TWO_LEVEL (pressure): needs poro_desc.coarse with the pressure interpolation (ptr_p / node_p / weight_p)");
@@ -588,12 +588,12 @@ int poro_pres_solve(poro_ctx *c, const poro_solver_opts *opts, poro_solve_info *
       const double om = opts->omega > 0 ? opts->omega : 1.0;
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { two_level_precondition_p(c, ja, jk, c->dinv_J.p, g, z, om); return false; };
       DiagVec dz; dz.full = c->dinv_J.p; dz.z = c->wz_p.p; dz.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
-      const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
+      const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P, c->pcg_hint_p);
       la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_DP), true);
       return rc;
     }
     DiagVec dv; dv.full = c->dinv_J.p; dv.inert = (c->cons_p.n || c->n_pdir) ? c->cons_p.inert.p : nullptr;
-    const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_DP), vec(c, PORO_VEC_RESIDUAL_P), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, nullptr, c->pcg_hint_p);
     la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_DP), true);              // constraints.distribute(solution_update) (:180)
     return rc;
   });
@@ -664,7 +664,7 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
       if (!c->wz_p.p) c->wz_p.alloc(c->n_p);
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { fdm_precondition_p(c, 1.0, kk, g, z); return false; };
       DiagVec dz; dz.full = c->dinv_M.p; dz.z = c->wz_p.p;
-      return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
+      return pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P, c->pcg_hint_proj);
     }
     if (opts->preconditioner == PORO_PREC_TWO_LEVEL) {
       if (!two_level_supported_p(c)) throw Error("PORO_PREC_TWO_LEVEL (projection): needs poro_desc.coarse with the pressure interpolation");
@@ -672,12 +672,12 @@ int poro_proj_solve(poro_ctx *c, int32_t entry, const poro_solver_opts *opts, po
       const double om = opts->omega > 0 ? opts->omega : 1.0;
       const std::function<bool(const double *, double *, double *)> P = [&](const double *g, double *z, double *) { two_level_precondition_p(c, 1.0, 0.0, c->dinv_M.p, g, z, om); return false; };
       DiagVec dz; dz.full = c->dinv_M.p; dz.z = c->wz_p.p; dz.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
-      const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P);
+      const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dz, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, &P, c->pcg_hint_proj);
       la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_STRAIN0 + entry), true);
       return rc;
     }
     DiagVec dv; dv.full = c->dinv_M.p; dv.inert = c->cons_p.n ? c->cons_p.inert.p : nullptr;
-    const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info);
+    const int rc = pcg(c, apply, c->n_p, c->comm.part.plane_p, vec(c, PORO_VEC_STRAIN0 + entry), vec(c, PORO_VEC_PROJ_RHS0 + entry), dv, c->wg_p.p, c->wd_p.p, c->wh_p.p, opts, info, nullptr, c->pcg_hint_proj);
     la_cons_expand(c->stream, c->cons_p, vec(c, PORO_VEC_STRAIN0 + entry), true);   // constraints.distribute (StrainProjector.h:216)
     return rc;
   });

@@ -117,7 +117,8 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
   // the extrapolation must not run away after an atypical solve (a warm restart that took 3 iterations, followed by a real step): never expect more than a quarter
   // above the last count, and nothing above it where an overshoot is expensive
   if (expect > 0) expect = std::min(expect, cheap_overshoot ? its_hint[0] + std::max(2, its_hint[0] / 4) : its_hint[0]);
-  int batch = expect > 0 ? (cheap_overshoot ? std::min(expect, 256) : std::max(1, expect - 1)) : (precond && !cheap_overshoot ? 1 : 4);   // no history: a poll (~15 us through the mailbox) every 4 iterations
+  const bool small = n <= 400000;     // launch-bound sizes: an ungated preconditioner application costs less than the idle time of a poll
+  int batch = expect > 0 ? (cheap_overshoot ? std::min(expect, 256) : std::max(1, expect - 1)) : (precond && !cheap_overshoot && !small ? 1 : 4);   // no history: a poll (~15 us through the mailbox) every 4 iterations
   while (true) {
     for (int k = 0; k < batch; ++k) {
       ++it;
@@ -138,7 +139,7 @@ int pcg(poro_ctx *c, const std::function<bool(const double *, double *, double *
     }
     post_and_wait(c, nullptr, 0, sc); hs = c->mailbox->sc;
     if (hs.done || hs.finishing) break;
-    if (expect > 0) batch = cheap_overshoot ? 3 : 1;
+    if (expect > 0) batch = cheap_overshoot ? 3 : small ? 2 : 1;
     else if (cheap_overshoot && precond) batch = 4;          // (an explicit preconditioner: a no-op iteration still costs ~8 launches)
     else if (batch < 32) batch *= 2;
   }
