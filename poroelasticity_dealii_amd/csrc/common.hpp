@@ -220,7 +220,7 @@ struct poro_ctx {
   poro::FdmOct fdm_oct;
   poro::FdmOct fdm_p_fused;          // the scalar Q1 systems through the same transform kernel (3D boxes, lines of <= 128 vertices)
   // two-level preconditioner (poro_desc.coarse): the underlying uniform box as a context of its own (same device and stream) + the node-wise interpolation P and its transpose
-  struct Interp { int64_t n_fine = 0, n_coarse = 0; bool long_rows_t = false; poro::DevBuf<int64_t> p_ptr, pt_ptr; poro::DevBuf<int32_t> p_col, pt_col; poro::DevBuf<double> p_w, pt_w; };   // P (rows = fine) and its transpose as CSR
+  struct Interp { int64_t n_fine = 0, n_coarse = 0; int lanes = 1, lanes_t = 1;   /* lanes per row of the interpolation kernels, from the mean row length */ poro::DevBuf<int64_t> p_ptr, pt_ptr; poro::DevBuf<int32_t> p_col, pt_col; poro::DevBuf<double> p_w, pt_w; };   // P (rows = fine) and its transpose as CSR
   struct TwoLevel : Interp { poro_ctx *box = nullptr; Interp pressure; } two_level;   // (the base part: displacement nodes; .pressure: pressure dofs, optional)
   bool borrowed_stream = false;     // (the box context of a two-level preconditioner runs on its parent's stream)
   poro::FdmU fdm_u; poro::DevBuf<double> fdmu_t1, fdmu_t2, wz_u; int fdm_u_state = 0 /* 0 unknown, 1 usable, -1 not separable */; std::string fdm_u_why;
@@ -248,9 +248,9 @@ namespace poro {
 void la_fill(hipStream_t s, double *x, double v, int64_t n);
 // copy n <= 16 doubles from `src` (device) and optionally *sc into the host mailbox, then publish sequence number `seq` (system-scope release)
 // node-wise sparse interpolation of a node-interleaved vector: out[(row, c)] = sum_k w[k] in[(col[k], c)] (prolongation by P, restriction by its transpose)
-void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, bool long_rows = false);
+void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, int lanes = 1);
 // z = omega D^-1 g + P z_c, zero on the inert dofs (additive two-level preconditioner)
-void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z);
+void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z, int lanes = 1);
 void la_copy_many(hipStream_t s, int count, double *const *dst, const double *const *src, const int64_t *n);   // several device-to-device copies in one launch
 void la_post(hipStream_t s, Mailbox *mb, unsigned long long seq, const double *src, int n, const PcgScalars *sc);
 void la_copy(hipStream_t s, double *y, const double *x, int64_t n);

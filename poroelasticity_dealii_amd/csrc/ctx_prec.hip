@@ -331,7 +331,8 @@ void fdm_precondition_u_slab(poro_ctx *c, const double *g, double *z, const PcgS
 static void upload_interp(poro_ctx::Interp &T, int64_t n_fine, int64_t n_coarse, const int64_t *ptr, const int32_t *node, const double *weight, const char *what) {
   T.n_fine = n_fine; T.n_coarse = n_coarse;
   const int64_t nnz = ptr[n_fine];
-  T.long_rows_t = nnz >= 4 * n_coarse;                                          // restriction rows of several entries on average: a lane group per row
+  const auto lanes_for = [](int64_t nnz, int64_t rows) { return nnz >= 6 * rows ? 8 : nnz >= 3 * rows ? 4 : 1; };   // mean row length -> lanes per row
+  T.lanes = lanes_for(nnz, n_fine); T.lanes_t = lanes_for(nnz, n_coarse);
   std::vector<int64_t> tp((size_t)n_coarse + 1, 0);
   for (int64_t k = 0; k < nnz; ++k) { const int32_t j = node[k]; if (j < 0 || j >= n_coarse) throw Error(std::string("poro_desc.coarse: ") + what + " node out of range"); tp[j + 1]++; }
   for (int64_t j = 0; j < n_coarse; ++j) tp[j + 1] += tp[j];
@@ -364,21 +365,21 @@ void two_level_precondition_p(poro_ctx *c, double a, double kappa, const double 
   build_fdm_p(H);
   if (!H->wz_p.p) H->wz_p.alloc(H->n_p);
   double *rc = H->wg_p.p, *zc = H->wz_p.p;
-  la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, 1, g, rc, T.long_rows_t);
+  la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, 1, g, rc, T.lanes_t);
   const double kk[3] = {kappa, kappa, kappa};
   fdm_precondition_p(H, a, kk, rc, zc);
-  la_two_level_combine(s, T.p_ptr.p, T.p_col.p, T.p_w.p, T.n_fine, 1, zc, g, dinv, (c->cons_p.n || c->n_pdir) ? c->cons_p.inert.p : nullptr, omega, z);
+  la_two_level_combine(s, T.p_ptr.p, T.p_col.p, T.p_w.p, T.n_fine, 1, zc, g, dinv, (c->cons_p.n || c->n_pdir) ? c->cons_p.inert.p : nullptr, omega, z, T.lanes);
 }
 void two_level_precondition_u(poro_ctx *c, const double *g, double *z, double omega) {
   Timed tm(c, "precondition_u_two_level");
   auto &T = c->two_level; poro_ctx *H = T.box; hipStream_t s = c->stream; const int dim = c->dim;
   build_fdm_u(H);
   double *rc = H->wg_u.p, *zc = H->wz_u.p;                                  // the box context's work vectors (it never solves anything itself)
-  la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, dim, g, rc, T.long_rows_t);              // r_H = P^T g
+  la_nodal_interp(s, T.pt_ptr.p, T.pt_col.p, T.pt_w.p, T.n_coarse, dim, g, rc, T.lanes_t);              // r_H = P^T g
   FdmOct &O = H->fdm_oct;
   if (O.built) { fdmo_from_nodal(s, O, rc, O.g.p); if (O.planar) fdmo_apply_planar(s, O, O.g.p, O.z.p); else fdmo_apply(s, O, O.g.p, O.z.p, O.t.p); fdmo_to_nodal(s, O, O.z.p, zc); }
   else fdm_precondition_u(H, rc, zc);                                         // z_H = blockdiag(A_H)^-1 r_H (zero on the box's Dirichlet faces)
-  la_two_level_combine(s, T.p_ptr.p, T.p_col.p, T.p_w.p, T.n_fine, dim, zc, g, c->dinv_u.p, c->cons_u.inert.p, omega, z);
+  la_two_level_combine(s, T.p_ptr.p, T.p_col.p, T.p_w.p, T.n_fine, dim, zc, g, c->dinv_u.p, c->cons_u.inert.p, omega, z, T.lanes);
 }
 
 void fdm_precondition_u(poro_ctx *c, const double *g, double *z) {

@@ -392,10 +392,11 @@ __global__ void __launch_bounds__(kBlock) k_nodal_interp(const int64_t *__restri
     out[t] = acc;
   }
 }
-// long rows (the restriction P^T of a refined block: up to (4k - 1)^dim entries per coarse node next to single-entry rows): LANES consecutive lanes share a row,
-// consecutive entries to consecutive lanes, partial sums folded with DPP-width shuffles
+// long rows (the restriction P^T of a refined block: up to (4k - 1)^dim entries per coarse node next to single-entry rows; the prolongation: 1 .. (k + 1)^dim): LANES
+// consecutive lanes share a row, consecutive entries to consecutive lanes, partial sums folded with shuffles (a fixed order: reproducible)
 template <int LANES>
-__global__ void __launch_bounds__(kBlock) k_nodal_interp_wide(const int64_t *__restrict__ ptr, const int32_t *__restrict__ col, const double *__restrict__ w, int64_t n_rows, int ncomp, const double *__restrict__ in, double *__restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_nodal_interp_wide(const int64_t *__restrict__ ptr, const int32_t *__restrict__ col, const double *__restrict__ w, int64_t n_rows, int ncomp, const double *__restrict__ in, double *__restrict__ out,
+                                                            const double *__restrict__ g, const double *__restrict__ dinv, const uint8_t *__restrict__ inert, double omega) {
   const int lane = threadIdx.x % LANES;
   const int64_t total = n_rows * ncomp, per_pass = (int64_t)gridDim.x * (kBlock / LANES);
   const int64_t last = ((total + per_pass - 1) / per_pass) * per_pass;          // whole groups stay in the loop together (the shuffles need every lane)
@@ -407,16 +408,23 @@ __global__ void __launch_bounds__(kBlock) k_nodal_interp_wide(const int64_t *__r
     }
 #pragma unroll
     for (int m = LANES / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, LANES);
-    if (lane == 0 && t < total) out[t] = acc;
+    if (lane == 0 && t < total) {
+      if (g) acc = (inert && inert[t]) ? 0.0 : fma(omega * dinv[t], g[t], acc);
+      out[t] = acc;
+    }
   }
 }
-void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, bool long_rows) {
+static void nodal_interp_launch(hipStream_t s, int lanes, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, const double *g, const double *dinv, const uint8_t *inert, double omega) {
   if (!n_rows) return;
-  if (long_rows) { constexpr int L = 8; hipLaunchKernelGGL(k_nodal_interp_wide<L>, grid_for(n_rows * ncomp * L), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out); return; }
-  hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, (const double *)nullptr, (const double *)nullptr, (const uint8_t *)nullptr, 0.0);
+  if (lanes >= 8) hipLaunchKernelGGL(k_nodal_interp_wide<8>, grid_for(n_rows * ncomp * 8), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
+  else if (lanes >= 4) hipLaunchKernelGGL(k_nodal_interp_wide<4>, grid_for(n_rows * ncomp * 4), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
+  else hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
 }
-void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z) {
-  if (n_rows) hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, zc, z, g, dinv, inert, omega);
+void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, int lanes) {
+  nodal_interp_launch(s, lanes, ptr, col, w, n_rows, ncomp, in, out, nullptr, nullptr, nullptr, 0.0);
+}
+void la_two_level_combine(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *zc, const double *g, const double *dinv, const uint8_t *inert, double omega, double *z, int lanes) {
+  nodal_interp_launch(s, lanes, ptr, col, w, n_rows, ncomp, zc, z, g, dinv, inert, omega);
 }
 struct ManyPairs { const double *y[3], *b[3]; };
 __global__ void __launch_bounds__(kBlock) k_residual_norms_many(ManyPairs V, int nb, int64_t n, double *partials) {

@@ -264,9 +264,9 @@ template <int dim> class PoroElasticProblem {
         rc.preconditioner == PORO_PREC_SSOR ? PORO_PREC_SSOR : rc.preconditioner_p >= 0 ? rc.preconditioner_p
         : poro_supports_preconditioner(context(), 1, PORO_PREC_FDM) ? PORO_PREC_FDM : PORO_PREC_JACOBI;
     // the pressure Jacobian's stiffness part makes Jacobi-CG grow with 1/h: the two-level form where the mesh carries a coarse space.  (The projection's mass matrix
-    // is well conditioned under Jacobi on any mesh: 12-15 iterations, fewer than the additive two-level form needs; below ~8k pressure dofs a CG iteration is
+    // is well conditioned under Jacobi on any mesh: 12-15 iterations, fewer than the additive two-level form needs; below ~4k pressure dofs a CG iteration is
     // launch-bound and the two-level form's extra launches cost more than the iterations it saves - profiles/r03_refined_box_step.json.)
-    if (rc.preconditioner != PORO_PREC_SSOR && rc.preconditioner_p < 0 && pressure_solver.control.preconditioner == PORO_PREC_JACOBI && pd->d.n_dofs_p >= 8192 && poro_supports_preconditioner(context(), 1, PORO_PREC_TWO_LEVEL))
+    if (rc.preconditioner != PORO_PREC_SSOR && rc.preconditioner_p < 0 && pressure_solver.control.preconditioner == PORO_PREC_JACOBI && pd->d.n_dofs_p >= 4096 && poro_supports_preconditioner(context(), 1, PORO_PREC_TWO_LEVEL))
       pressure_solver.control.preconditioner = PORO_PREC_TWO_LEVEL;
     setup_dofs();                                          // :308
     pressure_solver.solution = rc.p_init;                  // :311

@@ -141,7 +141,7 @@ def test_gmsh_mesh_two_level_preconditioner_is_mesh_independent():
     same boundary conditions (ids translated side by side) as coarse space; PREC_TWO_LEVEL = Jacobi + block fast diagonalisation of that box through the FE interpolation.
     The CG iteration count stays flat under refinement (Jacobi's doubles), the solution is the oracle's"""
     from common import BC_2D, DOMAIN_MSH, material
-    counts, jacobi = [], []
+    counts, jacobi, pres = [], [], []
     for r in (0, 1, 2, 3):
         P = pk.Problem.gmsh(DOMAIN_MSH, 2, material(), BC_2D, refine=r)
         assert P.desc.coarse.enabled and not P.desc.box.enabled
@@ -158,6 +158,19 @@ def test_gmsh_mesh_two_level_preconditioner_is_mesh_independent():
             rc, info = F.disp_solve(abs_tol=1e-14, rel_tol=1e-10, max_iter=50000)
             assert rc == 0 and np.linalg.norm(F.get(pk.VEC_U) - u) <= 1e-7 * np.linalg.norm(u)
             jacobi.append(info.iterations)
+            # the pressure Jacobian through the same auxiliary box (vertex interpolation): same update as Jacobi-CG, fewer iterations once the mesh is fine
+            m = F.n_p
+            for k, v in {pk.VEC_P: 10e6 * (1 + 0.05 * np.sin(0.37 * np.arange(m))), pk.VEC_P_OLD: 10e6 * (1 + 0.05 * np.sin(0.2 * np.arange(m))),
+                         pk.VEC_EPSV: -2e-6 * (1 + 0.3 * np.sin(0.5 * np.arange(m))), pk.VEC_EPSV0: -2e-6 * np.ones(m)}.items():
+                F.set(k, v)
+            assert F.supports_preconditioner(1, pk.PREC_TWO_LEVEL)
+            F.pres_assemble_residual(60.0); F.pres_assemble_jacobian(60.0)
+            rc, two = F.pres_solve(rel_tol=1e-10, max_iter=500, prec=pk.PREC_TWO_LEVEL)
+            assert rc == 0
+            dp = F.get(pk.VEC_DP); F.fill(pk.VEC_DP, 0.0)
+            rc, jac = F.pres_solve(rel_tol=1e-10, max_iter=20000)
+            assert rc == 0 and np.linalg.norm(F.get(pk.VEC_DP) - dp) <= 1e-7 * np.linalg.norm(dp)
+            pres.append((two.iterations, jac.iterations))
             if O is not None:
                 O.set(pk.VEC_P, p); O.disp_assemble_system(True)
                 assert O.disp_solve(abs_tol=1e-14, rel_tol=1e-12, max_iter=50000)[0] == 0
@@ -169,3 +182,5 @@ def test_gmsh_mesh_two_level_preconditioner_is_mesh_independent():
     print("Gmsh mesh, two-level CG iterations per refinement:", counts, "Jacobi:", jacobi)
     assert all(b <= 1.3 * a for a, b in zip(counts, counts[1:])), counts
     assert counts[-1] < jacobi[-1] / 5, (counts, jacobi)
+    print("Gmsh mesh, pressure CG iterations (two-level, Jacobi) per refinement:", pres)
+    assert pres[-1][0] <= 1.3 * pres[-2][0] and pres[-1][0] < pres[-1][1], pres
