@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <fstream>
 #include <limits>
@@ -536,8 +537,15 @@ inline bool attach_auxiliary_box(ProblemData &P, int k_u) {
     if (it == side_of_id.end()) side_of_id[m.bface_id[f]] = side; else if (it->second != side) return false;
   }
   auto translate = [&](std::vector<int32_t> &labels) { for (auto &l : labels) { auto it = side_of_id.find(l); l = it == side_of_id.end() ? -1 - l : it->second; } };   // (ids no edge carries: to ids the box does not have)
-  const int nside = std::max(2, (int)std::lround(std::sqrt((double)m.n_cells() * size[0] / size[1])));
-  int n[3] = {nside, std::max(2, (int)std::lround((double)m.n_cells() / nside)), 1};
+  // resolution of the auxiliary box: as many cells as the mesh, divided by coarsen^2 (the spaces need not be nested; a coarser box makes the coarse solve cheaper
+  // - its transforms cost O(n^3) per application - at the price of a few CG iterations; PORO_AUX_BOX_COARSEN overrides the default)
+  // measured on the bundled grid (profiles/r03_gmsh_step.json): half the resolution costs 5 of 51 CG iterations per step and saves 12 % of the step at 102 400 cells;
+  // a third of it costs 25 iterations.  Small meshes keep the full resolution (the coarse solve is launch-bound there anyway).
+  static const double coarsen_env = [] { const char *e = std::getenv("PORO_AUX_BOX_COARSEN"); const double v = e ? std::atof(e) : 0.0; return v >= 1.0 ? v : 0.0; }();
+  const double coarsen = coarsen_env > 0 ? coarsen_env : (m.n_cells() >= 20000 ? 2.0 : 1.0);
+  const double target = (double)m.n_cells() / (coarsen * coarsen);
+  const int nside = std::max(2, (int)std::lround(std::sqrt(target * size[0] / size[1])));
+  int n[3] = {nside, std::max(2, (int)std::lround(target / nside)), 1};
   double origin[3] = {lo[0], lo[1], 0}, h[3] = {size[0] / n[0], size[1] / n[1], 1};
   P.coarse.reset(new ProblemData()); ProblemData &C = *P.coarse;
   C.bc = P.bc; C.mat = P.mat;
