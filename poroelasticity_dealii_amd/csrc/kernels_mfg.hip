@@ -270,6 +270,107 @@ k_mfg3_sf(AsmArgs a, Sf1D T, const int32_t *__restrict__ cells, int n_cells, con
   }
 }
 
+
+// ---- the same for quadrilaterals (2D, Q1 / Q2): 16 lanes per Q2 cell (9 points), 4 per Q1 cell; 16 / 64 cells per workgroup -----------------------------------------
+template <int N1>
+__global__ void __launch_bounds__(256)
+k_mfg2_sf(AsmArgs a, Sf1D T, const int32_t *__restrict__ cells, int n_cells, const double *__restrict__ x, double *__restrict__ y, int constrained) {
+  constexpr int NP = N1 * N1, LPC = N1 == 3 ? 16 : 4, CPW = 256 / LPC;
+  __shared__ double sU[CPW][2][NP], sA[CPW][4][NP], sX[CPW][8];
+  const int tid = threadIdx.x, cs = tid / LPC, p = tid - cs * LPC;
+  const int64_t slot = (int64_t)blockIdx.x * CPW + cs;
+  const bool live = p < NP && slot < n_cells;
+  const int64_t cell = slot < n_cells ? cells[slot] : cells[0];
+  const int i = p % N1, j = (p / N1) % N1;
+  const double lam = a.mat.lame_lambda, G = a.mat.shear_G;
+  int32_t dof[2] = {0, 0}; bool dir[2] = {true, true};
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      dof[c] = a.cell_dofs_u[cell * (2 * NP) + p * 2 + c];
+      dir[c] = constrained && a.dir_mask[dof[c]];
+      sU[cs][c][p] = dir[c] ? 0.0 : x[dof[c]];
+    }
+  }
+  if (slot < n_cells) for (int e = p; e < 8; e += LPC) sX[cs][e] = a.cell_X[cell * 8 + e];
+  wave_sync();
+  if (live) {                                             // sweep along xi: thread (qi = i, j)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { double vN = 0, vD = 0;
+#pragma unroll
+      for (int m = 0; m < N1; ++m) { const double u = sU[cs][c][m + N1 * j]; vN = fma(T.N[i][m], u, vN); vD = fma(T.D[i][m], u, vD); }
+      sA[cs][2 * c][p] = vN; sA[cs][2 * c + 1][p] = vD; }
+  }
+  wave_sync();
+  double R[2][2];                                         // reference-space gradient at the lane's quadrature point (qi = i, qj = j)
+#pragma unroll
+  for (int c = 0; c < 2; ++c) { double gx = 0, gy = 0;
+    if (live) {
+#pragma unroll
+      for (int m = 0; m < N1; ++m) { gx = fma(T.N[j][m], sA[cs][2 * c + 1][i + N1 * m], gx); gy = fma(T.D[j][m], sA[cs][2 * c][i + N1 * m], gy); }
+    }
+    R[c][0] = gx; R[c][1] = gy; }
+  double S[2][2];                                         // reference-space flux: S[c][b] = sum_d sigma[c][d] Jinv[b][d] * JxW
+  {
+    const double lx[2] = {1.0 - T.xi[i], T.xi[i]}, ly[2] = {1.0 - T.xi[j], T.xi[j]}, dl[2] = {-1.0, 1.0};
+    double J[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int vi = v & 1, vj = v >> 1;
+      const double d0 = dl[vi] * ly[vj], d1 = lx[vi] * dl[vj];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { const double X = sX[cs][v * 2 + r]; J[r][0] = fma(X, d0, J[r][0]); J[r][1] = fma(X, d1, J[r][1]); }
+    }
+    const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0], id = live ? 1.0 / det : 0.0;
+    const double Ji[2][2] = {{J[1][1] * id, -J[0][1] * id}, {-J[1][0] * id, J[0][0] * id}};   // Ji[b][d] = d xi_b / d x_d
+    const double jxw = det * T.w[i] * T.w[j];
+    double g[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) g[c][d] = fma(R[c][0], Ji[0][d], R[c][1] * Ji[1][d]);
+    const double tr = g[0][0] + g[1][1];
+    double sg[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) sg[c][d] = jxw * (G * (g[c][d] + g[d][c]) + (c == d ? lam * tr : 0.0));
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) S[c][b] = fma(sg[c][0], Ji[b][0], sg[c][1] * Ji[b][1]);
+  }
+  wave_sync();
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { sA[cs][2 * c][p] = S[c][0]; sA[cs][2 * c + 1][p] = S[c][1]; }
+  }
+  wave_sync();
+  double F[2][2];
+  if (live) {                                             // contract qj -> node b = j: thread (qi, b)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { double f0 = 0, f1 = 0;
+#pragma unroll
+      for (int m = 0; m < N1; ++m) { f0 = fma(T.N[m][j], sA[cs][2 * c][i + N1 * m], f0); f1 = fma(T.D[m][j], sA[cs][2 * c + 1][i + N1 * m], f1); }
+      F[c][0] = f0; F[c][1] = f1; }
+  }
+  wave_sync();
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { sA[cs][2 * c][p] = F[c][0]; sA[cs][2 * c + 1][p] = F[c][1]; }
+  }
+  wave_sync();
+  if (live) {                                             // contract qi -> node a = i; coloured scatter
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      double v = 0;
+#pragma unroll
+      for (int m = 0; m < N1; ++m) { v = fma(T.D[m][i], sA[cs][2 * c][m + N1 * j], v); v = fma(T.N[m][i], sA[cs][2 * c + 1][m + N1 * j], v); }
+      if (!dir[c]) y[dof[c]] += v;
+    }
+  }
+}
+
 Sf1D sf_tables(int k) {
   Sf1D T{};
   const int n1 = k + 1;
@@ -290,11 +391,17 @@ void mfg_apply(hipStream_t s, const AsmArgs &a, const int32_t *color_cells, cons
   if (a.fe.nq_u > kMaxNq || a.dpc_u > kMaxDpc) throw Error("mfg_apply: element too large");
   PORO_HIP(hipMemsetAsync(y, 0, n_u * sizeof(double), s));
   static const bool no_sf = std::getenv("PORO_MFG_NO_SUMFAC") != nullptr;
-  const bool sf = a.dim == 3 && mode == 0 && !no_sf && (a.k_u == 1 || a.k_u == 2);
+  const bool sf = (a.dim == 3 || a.dim == 2) && mode == 0 && !no_sf && (a.k_u == 1 || a.k_u == 2);
   const Sf1D T = sf ? sf_tables(a.k_u) : Sf1D{};
   for (size_t k = 0; k + 1 < color_off.size(); ++k) {
     const int64_t nc = color_off[k + 1] - color_off[k];
     if (!nc) continue;
+    if (sf && a.dim == 2) {
+      const int cpw = a.k_u == 2 ? 16 : 64;
+      if (a.k_u == 2) hipLaunchKernelGGL(k_mfg2_sf<3>, (unsigned)((nc + cpw - 1) / cpw), 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
+      else hipLaunchKernelGGL(k_mfg2_sf<2>, (unsigned)((nc + cpw - 1) / cpw), 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
+      continue;
+    }
     if (sf) {
       const int cpw = a.k_u == 2 ? 8 : 32;
       if (a.k_u == 2) hipLaunchKernelGGL(k_mfg3_sf<3>, (unsigned)((nc + cpw - 1) / cpw), 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
