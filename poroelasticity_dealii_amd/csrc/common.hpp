@@ -190,6 +190,7 @@ struct poro_ctx {
   // mesh / dof data
   poro::DevBuf<int32_t> cell_dofs_u, cell_dofs_p, color_cells;
   poro::DevBuf<double> cell_X, tables;
+  poro::DevBuf<double> cell_geo;          // 3D meshes whose cells are all parallelepipeds: J^-1 (9, row-major [b][d] = d xi_b / d x_d) and det J per cell (kernels_mfg.hip)
   poro::FeTablesDev fe{};
   std::vector<int64_t> color_off;            // host offsets into color_cells
   poro::DevBuf<uint8_t> dir_mask, node_mask; poro::DevBuf<double> dir_val; poro::DevBuf<int32_t> dir_dofs;
@@ -312,6 +313,7 @@ struct AsmArgs {
   int dim, k_u, ns_u, ns_p, nv, dpc_u;
   FeTablesDev fe;
   const int32_t *cell_dofs_u, *cell_dofs_p; const double *cell_X;
+  const double *cell_geo;   // [n_cells][10] or null (see poro_ctx::cell_geo)
   const uint8_t *dir_mask; const double *dir_val;
   poro_material mat;
   int interleaved_u;   // dof = node * dim + component everywhere (lets K-asm-u look CSR positions up per node pair)

@@ -196,7 +196,7 @@ int64_t owned(poro_ctx *c, int64_t n, int64_t plane) {
 AsmArgs asm_args(poro_ctx *c) {
   AsmArgs a{};
   a.dim = c->dim; a.k_u = c->k_u; a.ns_u = c->ns_u; a.ns_p = c->ns_p; a.nv = c->nv; a.dpc_u = c->dpc_u; a.fe = c->fe;
-  a.cell_dofs_u = c->cell_dofs_u.p; a.cell_dofs_p = c->cell_dofs_p.p; a.cell_X = c->cell_X.p; a.dir_mask = c->dir_mask.p; a.dir_val = c->dir_val.p; a.mat = c->mat;
+  a.cell_dofs_u = c->cell_dofs_u.p; a.cell_dofs_p = c->cell_dofs_p.p; a.cell_X = c->cell_X.p; a.cell_geo = c->cell_geo.p; a.dir_mask = c->dir_mask.p; a.dir_val = c->dir_val.p; a.mat = c->mat;
   a.interleaved_u = c->interleaved_u;
   return a;
 }

@@ -193,7 +193,28 @@ void setup(poro_ctx *c, const poro_desc *d) {
   c->cell_dofs_u.upload(d->cell_dofs_u, c->n_cells * c->dpc_u); c->cell_dofs_p.upload(d->cell_dofs_p, c->n_cells * c->dpc_p);
   { std::vector<double> X((size_t)c->n_cells * c->nv * dim);
     for (int64_t i = 0; i < c->n_cells * c->nv; ++i) for (int k = 0; k < dim; ++k) X[i * dim + k] = d->vertex_coords[(int64_t)d->cell_vertices[i] * dim + k];
-    c->cell_X.upload(X); }
+    c->cell_X.upload(X);
+    // affine cells (graded / locally refined boxes, lattice-like Gmsh grids): MappingQ1's Jacobian is one matrix per cell - the sum-factorised operator kernel reads
+    // its inverse instead of forming it from the eight vertices at every quadrature point
+    if (dim == 3 && c->n_cells > 0) {
+      std::vector<double> geo((size_t)c->n_cells * 10); bool affine = true;
+      for (int64_t e = 0; e < c->n_cells && affine; ++e) {
+        const double *x = X.data() + e * 24; double J[3][3], scale = 0;
+        for (int r = 0; r < 3; ++r) { J[r][0] = x[3 + r] - x[r]; J[r][1] = x[6 + r] - x[r]; J[r][2] = x[12 + r] - x[r]; scale = std::max({scale, std::fabs(J[r][0]), std::fabs(J[r][1]), std::fabs(J[r][2])}); }
+        for (int v = 0; v < 8 && affine; ++v) for (int r = 0; r < 3; ++r) {
+          const double want = x[r] + (v & 1) * J[r][0] + ((v >> 1) & 1) * J[r][1] + (v >> 2) * J[r][2];
+          if (std::fabs(x[v * 3 + r] - want) > 1e-13 * scale) affine = false;
+        }
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = 1.0 / det; double *g = geo.data() + e * 10;
+        g[0] = c00 * id; g[1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; g[2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+        g[3] = c01 * id; g[4] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; g[5] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+        g[6] = c02 * id; g[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; g[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id; g[9] = det;
+        if (!(det > 0)) affine = false;
+      }
+      static const bool no_affine = std::getenv("PORO_MFG_NO_AFFINE") != nullptr;
+      if (affine && !no_affine) c->cell_geo.upload(geo);
+    } }
   { std::vector<int32_t> cells; colour_cells(c->n_cells, d->n_vertices, c->nv, d->cell_vertices, cells, c->color_off); c->color_cells.upload(cells); }
   { std::vector<uint8_t> m(c->n_u, 0); std::vector<double> v(c->n_u, 0.0);
     for (int64_t i = 0; i < d->n_dirichlet; ++i) { const int32_t dof = d->dirichlet_dof[i]; if (dof < 0 || dof >= c->n_u) throw Error("dirichlet_dof out of range"); m[dof] = 1; v[dof] = d->dirichlet_value[i]; }

@@ -130,7 +130,7 @@ struct Sf1D { double N[3][3], D[3][3], w[3], xi[3]; };   // [quadrature point][n
 // every exchange of the sum-factorised kernel stays inside one cell's lanes, i.e. inside one wavefront (32 or 8 lanes per cell): LDS operations of a wave complete in
 // issue order, so a compiler-level fence replaces the workgroup barrier and the four waves of a workgroup drift apart freely (645 -> 626 us at 72^3 cells)
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-template <int N1>
+template <int N1, bool AFFINE>
 __global__ void __launch_bounds__(256)
 k_mfg3_sf(AsmArgs a, Sf1D T, const int32_t *__restrict__ cells, int n_cells, const double *__restrict__ x, double *__restrict__ y, int constrained) {
   constexpr int NP = N1 * N1 * N1, LPC = N1 == 3 ? 32 : 8, CPW = 256 / LPC;
@@ -150,7 +150,8 @@ k_mfg3_sf(AsmArgs a, Sf1D T, const int32_t *__restrict__ cells, int n_cells, con
       sU[cs][c][p] = dir[c] ? 0.0 : x[dof[c]];
     }
   }
-  if (slot < n_cells) for (int e = p; e < 24; e += LPC) sX[cs][e] = a.cell_X[cell * 24 + e];
+  if constexpr (AFFINE) { if (slot < n_cells) for (int e = p; e < 10; e += LPC) sX[cs][e] = a.cell_geo[cell * 10 + e]; }
+  else if (slot < n_cells) for (int e = p; e < 24; e += LPC) sX[cs][e] = a.cell_X[cell * 24 + e];
   wave_sync();
   double R[3][3];                                         // reference-space gradient of u_h at the lane's quadrature point
   {
@@ -186,6 +187,14 @@ k_mfg3_sf(AsmArgs a, Sf1D T, const int32_t *__restrict__ cells, int n_cells, con
   // MappingQ1 at the point: J[a][b] = sum_v X_v[a] dN_v / dxi_b, N_v trilinear (vertices lexicographic)
   double S[3][3];                                         // reference-space flux: S[c][b] = sum_d sigma[c][d] Jinv[b][d] * JxW
   {
+    double Ji[3][3], det;                                 // Ji[b][d] = d xi_b / d x_d
+    if constexpr (AFFINE) {                               // one Jacobian per cell, inverted at set-up
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) Ji[b][d] = live ? sX[cs][3 * b + d] : 0.0;
+      det = sX[cs][9];
+    } else {
     const double lx[2] = {1.0 - T.xi[i], T.xi[i]}, ly[2] = {1.0 - T.xi[j], T.xi[j]}, lz[2] = {1.0 - T.xi[k], T.xi[k]}, dl[2] = {-1.0, 1.0};
     double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
@@ -196,11 +205,11 @@ k_mfg3_sf(AsmArgs a, Sf1D T, const int32_t *__restrict__ cells, int n_cells, con
       for (int r = 0; r < 3; ++r) { const double X = sX[cs][v * 3 + r]; J[r][0] = fma(X, d0, J[r][0]); J[r][1] = fma(X, d1, J[r][1]); J[r][2] = fma(X, d2, J[r][2]); }
     }
     const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = live ? 1.0 / det : 0.0;
-    double Ji[3][3];                                      // Ji[b][d] = d xi_b / d x_d
+    det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02; const double id = live ? 1.0 / det : 0.0;
     Ji[0][0] = c00 * id; Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
     Ji[1][0] = c01 * id; Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
     Ji[2][0] = c02 * id; Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    }
     const double jxw = det * T.w[i] * T.w[j] * T.w[k];
     double g[3][3], tr = 0;                               // g[c][d] = d u_c / d x_d
 #pragma unroll
@@ -403,9 +412,11 @@ void mfg_apply(hipStream_t s, const AsmArgs &a, const int32_t *color_cells, cons
       continue;
     }
     if (sf) {
-      const int cpw = a.k_u == 2 ? 8 : 32;
-      if (a.k_u == 2) hipLaunchKernelGGL(k_mfg3_sf<3>, (unsigned)((nc + cpw - 1) / cpw), 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
-      else hipLaunchKernelGGL(k_mfg3_sf<2>, (unsigned)((nc + cpw - 1) / cpw), 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
+      const int cpw = a.k_u == 2 ? 8 : 32; const unsigned grid = (unsigned)((nc + cpw - 1) / cpw);
+      if (a.k_u == 2 && a.cell_geo) hipLaunchKernelGGL((k_mfg3_sf<3, true>), grid, 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
+      else if (a.k_u == 2) hipLaunchKernelGGL((k_mfg3_sf<3, false>), grid, 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
+      else if (a.cell_geo) hipLaunchKernelGGL((k_mfg3_sf<2, true>), grid, 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
+      else hipLaunchKernelGGL((k_mfg3_sf<2, false>), grid, 256, 0, s, a, T, color_cells + color_off[k], (int)nc, x, y, constrained ? 1 : 0);
       continue;
     }
     if (a.dim == 2) hipLaunchKernelGGL(k_mfg<2>, (unsigned)nc, 64, 0, s, a, color_cells + color_off[k], x, y, constrained ? 1 : 0, mode);
