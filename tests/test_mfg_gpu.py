@@ -184,3 +184,32 @@ def test_gmsh_mesh_two_level_preconditioner_is_mesh_independent():
     assert counts[-1] < jacobi[-1] / 5, (counts, jacobi)
     print("Gmsh mesh, pressure CG iterations (two-level, Jacobi) per refinement:", pres)
     assert pres[-1][0] <= 1.3 * pres[-2][0] and pres[-1][0] < pres[-1][1], pres
+
+
+def test_general_hexahedra_path_without_the_affine_shortcut():
+    """every mesh provider of this repo makes parallelepipeds, so the library reads one pre-inverted Jacobian per cell (poro_ctx::cell_geo); the kernel variant for general
+    hexahedra (MappingQ1's Jacobian from the eight vertices at every quadrature point) stays covered by a run with PORO_MFG_NO_AFFINE=1 - the switch is read once per
+    process, hence the child process.  Same operator as the oracle's, Q1 and Q2"""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import poroelasticity_dealii_amd as pk, oracle_py
+from common import BC_3D, REF, material
+for deg, n, grading in ((2, (4, 3, 5), (1.0, 0.5, -0.7)), (1, (5, 4, 6), (0.8, 0.0, 1.2))):
+    P = pk.Problem.graded_box(3, list(n), [10.0] * 3, deg, material(), BC_3D, list(grading))
+    O = oracle_py.Oracle(P, hoisted=True); F = pk.Context(P, 0, pk.OP_MATRIX_FREE)
+    p = REF["p_init"] * (1 + 0.2 * np.sin(0.37 * np.arange(F.n_p)))
+    for S in (F, O):
+        S.set(pk.VEC_P, p); S.disp_assemble_system(True)
+    x = np.sin(0.37 * np.arange(F.n_u))
+    yo, yf = O.apply(pk.MAT_A_U, x), F.apply(pk.MAT_A_U, x)
+    err = np.abs(yf - yo).max() / np.abs(yo).max()
+    assert err <= 1e-12, err
+    F.close(); O.close(); P.close()
+print("general-hexahedra path ok")
+''' % (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PORO_MFG_NO_AFFINE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "general-hexahedra path ok" in r.stdout, r.stdout + r.stderr
