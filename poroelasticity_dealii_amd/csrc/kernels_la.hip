@@ -394,30 +394,49 @@ __global__ void __launch_bounds__(kBlock) k_nodal_interp(const int64_t *__restri
 }
 // long rows (the restriction P^T of a refined block: up to (4k - 1)^dim entries per coarse node next to single-entry rows; the prolongation: 1 .. (k + 1)^dim): LANES
 // consecutive lanes share a row, consecutive entries to consecutive lanes, partial sums folded with shuffles (a fixed order: reproducible)
-template <int LANES>
-__global__ void __launch_bounds__(kBlock) k_nodal_interp_wide(const int64_t *__restrict__ ptr, const int32_t *__restrict__ col, const double *__restrict__ w, int64_t n_rows, int ncomp, const double *__restrict__ in, double *__restrict__ out,
+template <int LANES, int NC>
+__global__ void __launch_bounds__(kBlock) k_nodal_interp_wide(const int64_t *__restrict__ ptr, const int32_t *__restrict__ col, const double *__restrict__ w, int64_t n_rows, const double *__restrict__ in, double *__restrict__ out,
                                                             const double *__restrict__ g, const double *__restrict__ dinv, const uint8_t *__restrict__ inert, double omega) {
+  // a lane group per ROW: an entry's column and weight are read once for the NC components of the node (adjacent in memory)
   const int lane = threadIdx.x % LANES;
-  const int64_t total = n_rows * ncomp, per_pass = (int64_t)gridDim.x * (kBlock / LANES);
-  const int64_t last = ((total + per_pass - 1) / per_pass) * per_pass;          // whole groups stay in the loop together (the shuffles need every lane)
-  for (int64_t t = (int64_t)blockIdx.x * (kBlock / LANES) + threadIdx.x / LANES; t < last; t += per_pass) {
-    double acc = 0;
-    if (t < total) {
-      const int64_t row = t / ncomp; const int c = (int)(t - row * ncomp);
-      for (int64_t k = ptr[row] + lane; k < ptr[row + 1]; k += LANES) acc = fma(w[k], in[(int64_t)col[k] * ncomp + c], acc);
+  const int64_t per_pass = (int64_t)gridDim.x * (kBlock / LANES);
+  const int64_t last = ((n_rows + per_pass - 1) / per_pass) * per_pass;        // whole groups stay in the loop together (the shuffles need every lane)
+  for (int64_t row = (int64_t)blockIdx.x * (kBlock / LANES) + threadIdx.x / LANES; row < last; row += per_pass) {
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0;
+    if (row < n_rows) {
+      for (int64_t k = ptr[row] + lane; k < ptr[row + 1]; k += LANES) {
+        const double wk = w[k]; const double *v = in + (int64_t)col[k] * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = fma(wk, v[c], acc[c]);
+      }
     }
 #pragma unroll
-    for (int m = LANES / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, LANES);
-    if (lane == 0 && t < total) {
-      if (g) acc = (inert && inert[t]) ? 0.0 : fma(omega * dinv[t], g[t], acc);
-      out[t] = acc;
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int m = LANES / 2; m >= 1; m >>= 1) acc[c] += __shfl_xor(acc[c], m, LANES);
+    if (row < n_rows && lane < NC) {                       // lane c stores component c
+      double v = acc[0];
+#pragma unroll
+      for (int c = 1; c < NC; ++c) if (lane == c) v = acc[c];
+      const int64_t t = row * NC + lane;
+      if (g) v = (inert && inert[t]) ? 0.0 : fma(omega * dinv[t], g[t], v);
+      out[t] = v;
     }
   }
 }
+template <int LANES> static void nodal_interp_wide(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, const double *g, const double *dinv, const uint8_t *inert, double omega) {
+  const unsigned grid = grid_for(n_rows * LANES);
+  if (ncomp == 1) hipLaunchKernelGGL((k_nodal_interp_wide<LANES, 1>), grid, kBlock, 0, s, ptr, col, w, n_rows, in, out, g, dinv, inert, omega);
+  else if (ncomp == 2) hipLaunchKernelGGL((k_nodal_interp_wide<LANES, 2>), grid, kBlock, 0, s, ptr, col, w, n_rows, in, out, g, dinv, inert, omega);
+  else hipLaunchKernelGGL((k_nodal_interp_wide<LANES, 3>), grid, kBlock, 0, s, ptr, col, w, n_rows, in, out, g, dinv, inert, omega);
+}
 static void nodal_interp_launch(hipStream_t s, int lanes, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, const double *g, const double *dinv, const uint8_t *inert, double omega) {
   if (!n_rows) return;
-  if (lanes >= 8) hipLaunchKernelGGL(k_nodal_interp_wide<8>, grid_for(n_rows * ncomp * 8), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
-  else if (lanes >= 4) hipLaunchKernelGGL(k_nodal_interp_wide<4>, grid_for(n_rows * ncomp * 4), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
+  if (ncomp < 1 || ncomp > 3) throw Error("nodal interpolation: 1..3 components per node");
+  if (lanes >= 8) nodal_interp_wide<8>(s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
+  else if (lanes >= 4) nodal_interp_wide<4>(s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
   else hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
 }
 void la_nodal_interp(hipStream_t s, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, int lanes) {
