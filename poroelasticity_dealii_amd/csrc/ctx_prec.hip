@@ -335,6 +335,8 @@ static void upload_interp(poro_ctx::Interp &T, int64_t n_fine, int64_t n_coarse,
   T.lanes = lanes_for(nnz, n_fine); T.lanes_t = lanes_for(nnz, n_coarse);
   std::vector<int64_t> tp((size_t)n_coarse + 1, 0);
   for (int64_t k = 0; k < nnz; ++k) { const int32_t j = node[k]; if (j < 0 || j >= n_coarse) throw Error(std::string("poro_desc.coarse: ") + what + " node out of range"); tp[j + 1]++; }
+  { int64_t longest = 0; for (int64_t j = 0; j < n_coarse; ++j) longest = std::max(longest, tp[j + 1]);      // restriction: a few very long rows (refined block) beside single-entry ones
+    if (longest >= 48) T.lanes_t = std::max(T.lanes_t, 16); }                     // (measured on the refined 32^3 box and the Gmsh grid: 16 lanes 3 % ahead of 8, 32 lanes behind both)
   for (int64_t j = 0; j < n_coarse; ++j) tp[j + 1] += tp[j];
   std::vector<int32_t> tc((size_t)nnz); std::vector<double> tw((size_t)nnz); std::vector<int64_t> pos(tp.begin(), tp.end() - 1);
   for (int64_t i = 0; i < n_fine; ++i) {

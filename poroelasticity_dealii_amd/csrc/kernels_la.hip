@@ -435,7 +435,8 @@ template <int LANES> static void nodal_interp_wide(hipStream_t s, const int64_t 
 static void nodal_interp_launch(hipStream_t s, int lanes, const int64_t *ptr, const int32_t *col, const double *w, int64_t n_rows, int ncomp, const double *in, double *out, const double *g, const double *dinv, const uint8_t *inert, double omega) {
   if (!n_rows) return;
   if (ncomp < 1 || ncomp > 3) throw Error("nodal interpolation: 1..3 components per node");
-  if (lanes >= 8) nodal_interp_wide<8>(s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
+  if (lanes >= 16) nodal_interp_wide<16>(s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
+  else if (lanes >= 8) nodal_interp_wide<8>(s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
   else if (lanes >= 4) nodal_interp_wide<4>(s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
   else hipLaunchKernelGGL(k_nodal_interp, grid_for(n_rows * ncomp), kBlock, 0, s, ptr, col, w, n_rows, ncomp, in, out, g, dinv, inert, omega);
 }
